@@ -1,0 +1,1020 @@
+// Pattern compiler: PCRE-subset text -> syntax tree -> position automaton with boundary-condition
+// nodes -> flat tables (hg_db.h), plus required-literal ("factor") analysis that feeds the
+// streaming prefilter.  Host C++; replaces hs_compile_multi for the path at
+// hypergrep/lib/c/hyperscanner.c:126-142,154-167.
+//
+// Accept / reject frontier follows Hyperscan 5.4's documented "unsupported constructs" (no
+// look-around, back-references, atomic groups, possessive quantifiers, conditionals, recursion,
+// callouts, \G \K \X \R \C, unicode properties without UCP), rejects expressions that can match the
+// empty string (no HS_FLAG_ALLOWEMPTY), embedded start/end anchors outside multiline mode, and flag
+// bits other than CASELESS|DOTALL|MULTILINE|SINGLEMATCH.  Byte semantics throughout (no UTF-8 mode).
+#include "hg_compile.h"
+
+#include <algorithm>
+#include <array>
+#include <bitset>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+
+namespace {
+
+using ByteSet = std::bitset<256>;
+
+struct CompileError : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+// ---------------------------------------------------------------- truth tables for assertions
+uint32_t tt_from(bool (*pred)(uint32_t pc, uint32_t nc)) {
+  uint32_t t = 0;
+  for (uint32_t pc = 0; pc < 4; pc++)
+    for (uint32_t nc = 0; nc < 5; nc++)
+      if (pred(pc, nc)) t |= 1u << (pc * 5 + nc);
+  return t;
+}
+const uint32_t TT_BOL_ML = tt_from([](uint32_t pc, uint32_t) { return pc == HG_PC_START || pc == HG_PC_NL; });
+const uint32_t TT_BOL = tt_from([](uint32_t pc, uint32_t) { return pc == HG_PC_START; });
+const uint32_t TT_EOL_ML = tt_from([](uint32_t, uint32_t nc) { return nc == HG_NC_NL || nc == HG_NC_NLFINAL || nc == HG_NC_END; });
+const uint32_t TT_EOL = tt_from([](uint32_t, uint32_t nc) { return nc == HG_NC_NLFINAL || nc == HG_NC_END; });
+const uint32_t TT_EOD = tt_from([](uint32_t, uint32_t nc) { return nc == HG_NC_END; });
+const uint32_t TT_WB = tt_from([](uint32_t pc, uint32_t nc) { return (pc == HG_PC_WORD) != (nc == HG_NC_WORD); });
+const uint32_t TT_NWB = HG_TT_ALL & ~TT_WB;
+
+// ---------------------------------------------------------------- syntax tree
+struct Node {
+  enum Kind { Empty, Class, Cat, Alt, Rep, Assert } kind = Empty;
+  ByteSet cls;             // Class
+  uint32_t tt = 0;         // Assert: truth table
+  bool start_anchor = false, end_anchor = false;  // Assert: non-multiline ^ \A / $ \Z \z
+  int min = 0, max = 0;    // Rep (max < 0: unbounded)
+  std::vector<std::unique_ptr<Node>> kids;
+};
+using NodeP = std::unique_ptr<Node>;
+
+NodeP make(Node::Kind k) {
+  auto n = std::make_unique<Node>();
+  n->kind = k;
+  return n;
+}
+
+void add_caseless(ByteSet &s) {
+  for (int c = 'a'; c <= 'z'; c++) {
+    if (s[c]) s.set(c - 32);
+    if (s[c - 32]) s.set(c);
+  }
+}
+void set_range(ByteSet &s, int lo, int hi) {
+  for (int c = lo; c <= hi; c++) s.set(c);
+}
+ByteSet cls_digit() { ByteSet s; set_range(s, '0', '9'); return s; }
+ByteSet cls_word() { ByteSet s; set_range(s, '0', '9'); set_range(s, 'a', 'z'); set_range(s, 'A', 'Z'); s.set('_'); return s; }
+ByteSet cls_space() { ByteSet s; s.set(' '); set_range(s, 9, 13); return s; }
+ByteSet cls_hspace() { ByteSet s; s.set(9); s.set(' '); s.set(0xA0); return s; }
+ByteSet cls_vspace() { ByteSet s; set_range(s, 10, 13); s.set(0x85); return s; }
+
+// ---------------------------------------------------------------- parser
+class Parser {
+ public:
+  Parser(const std::string &text, uint32_t flags) : s_(text) {
+    caseless_ = flags & HG_FLAG_CASELESS;
+    dotall_ = flags & HG_FLAG_DOTALL;
+    multiline_ = flags & HG_FLAG_MULTILINE;
+  }
+
+  NodeP parse() {
+    NodeP root = alternation();
+    if (pos_ < s_.size()) throw CompileError("unmatched closing parenthesis");
+    return root;
+  }
+
+ private:
+  const std::string &s_;
+  size_t pos_ = 0;
+  bool caseless_ = false, dotall_ = false, multiline_ = false, extended_ = false;
+  int depth_ = 0;
+
+  bool eof() const { return pos_ >= s_.size(); }
+  unsigned char peek(size_t k = 0) const { return static_cast<unsigned char>(s_[pos_ + k]); }
+  bool has(size_t k) const { return pos_ + k < s_.size(); }
+
+  struct FlagState { bool i, s, m, x; };
+  FlagState save() const { return {caseless_, dotall_, multiline_, extended_}; }
+  void restore(const FlagState &f) { caseless_ = f.i; dotall_ = f.s; multiline_ = f.m; extended_ = f.x; }
+
+  NodeP byte_node(int b) const {
+    NodeP n = make(Node::Class);
+    n->cls.set(b);
+    if (caseless_) add_caseless(n->cls);
+    return n;
+  }
+
+  void skip_free_spacing() {
+    if (!extended_) return;
+    for (;;) {
+      while (!eof() && (peek() == ' ' || (peek() >= 9 && peek() <= 13))) pos_++;
+      if (!eof() && peek() == '#') {
+        while (!eof() && peek() != '\n') pos_++;
+        continue;
+      }
+      return;
+    }
+  }
+
+  NodeP alternation() {
+    NodeP alt = make(Node::Alt);
+    for (;;) {
+      alt->kids.push_back(sequence());
+      if (!eof() && peek() == '|') { pos_++; continue; }
+      break;
+    }
+    return alt;
+  }
+
+  NodeP sequence() {
+    NodeP cat = make(Node::Cat);
+    for (;;) {
+      skip_free_spacing();
+      if (eof() || peek() == '|' || peek() == ')') break;
+      if (peek() == '*' || peek() == '+' || peek() == '?') throw CompileError("quantifier with nothing to repeat");
+      std::vector<NodeP> atoms = atom();
+      if (atoms.empty()) continue;
+      // a quantifier binds to the last produced atom only (matters for \Q..\E runs)
+      NodeP last = std::move(atoms.back());
+      atoms.pop_back();
+      for (auto &a : atoms) cat->kids.push_back(std::move(a));
+      for (;;) {
+        skip_free_spacing();
+        if (eof()) break;
+        int mn, mx;
+        unsigned char q = peek();
+        if (q == '*') { mn = 0; mx = -1; pos_++; }
+        else if (q == '+') { mn = 1; mx = -1; pos_++; }
+        else if (q == '?') { mn = 0; mx = 1; pos_++; }
+        else if (q == '{') { if (!braces(mn, mx)) break; }
+        else break;
+        if (mx >= 0 && mx < mn) throw CompileError("numbers out of order in {} quantifier");
+        if (mn > 32767 || mx > 32767) throw CompileError("bounded repeat is too large");
+        if (!eof() && peek() == '+') throw CompileError("possessive quantifiers are not supported");
+        if (!eof() && peek() == '?') pos_++;  // lazy: identical set of match end offsets
+        if (last->kind == Node::Assert) throw CompileError("quantifier on a zero-width assertion");
+        NodeP rep = make(Node::Rep);
+        rep->min = mn;
+        rep->max = mx;
+        rep->kids.push_back(std::move(last));
+        last = std::move(rep);
+      }
+      cat->kids.push_back(std::move(last));
+    }
+    return cat;
+  }
+
+  bool braces(int &mn, int &mx) {
+    size_t q = pos_ + 1;
+    auto number = [&](long &v) {
+      int nd = 0;
+      v = 0;
+      while (q < s_.size() && s_[q] >= '0' && s_[q] <= '9') {
+        v = std::min<long>(v * 10 + (s_[q] - '0'), 100000);
+        q++;
+        nd++;
+      }
+      return nd;
+    };
+    long a, b;
+    if (!number(a)) return false;
+    if (q < s_.size() && s_[q] == '}') { b = a; q++; }
+    else if (q < s_.size() && s_[q] == ',') {
+      q++;
+      int nd = number(b);
+      if (q >= s_.size() || s_[q] != '}') return false;
+      q++;
+      if (!nd) b = -1;
+    } else return false;
+    pos_ = q;
+    mn = static_cast<int>(a);
+    mx = static_cast<int>(b);
+    return true;
+  }
+
+  static int hexval(int c) {
+    if (c >= '0' && c <= '9') return c - '0';
+    if (c >= 'a' && c <= 'f') return c - 'a' + 10;
+    if (c >= 'A' && c <= 'F') return c - 'A' + 10;
+    return -1;
+  }
+
+  // After a backslash: escapes denoting one byte. Returns -1 (position unchanged) if not such an escape.
+  int byte_escape(bool in_class) {
+    if (eof()) throw CompileError("pattern ends with a backslash");
+    unsigned char c = peek();
+    switch (c) {
+      case 'n': pos_++; return '\n';
+      case 'r': pos_++; return '\r';
+      case 't': pos_++; return '\t';
+      case 'f': pos_++; return '\f';
+      case 'a': pos_++; return 7;
+      case 'e': pos_++; return 27;
+      case 'b': if (in_class) { pos_++; return 8; } return -1;
+      case 'c': {
+        if (!has(1)) throw CompileError("\\c at end of pattern");
+        int x = peek(1);
+        if (x >= 'a' && x <= 'z') x -= 32;
+        pos_ += 2;
+        return x ^ 0x40;
+      }
+      case 'x': {
+        size_t q = pos_ + 1;
+        unsigned v = 0;
+        if (q < s_.size() && s_[q] == '{') {
+          q++;
+          int nd = 0;
+          while (q < s_.size() && hexval(static_cast<unsigned char>(s_[q])) >= 0) {
+            v = v * 16 + hexval(static_cast<unsigned char>(s_[q]));
+            if (v > 0xFF) throw CompileError("\\x{} value does not fit a byte (UTF-8 mode is not supported)");
+            q++;
+            nd++;
+          }
+          if (q >= s_.size() || s_[q] != '}' || !nd) throw CompileError("malformed \\x{}");
+          pos_ = q + 1;
+          return static_cast<int>(v);
+        }
+        int nd = 0;
+        while (nd < 2 && q < s_.size() && hexval(static_cast<unsigned char>(s_[q])) >= 0) {
+          v = v * 16 + hexval(static_cast<unsigned char>(s_[q]));
+          q++;
+          nd++;
+        }
+        pos_ = q;
+        return static_cast<int>(v);
+      }
+      default: break;
+    }
+    if (c >= '0' && c <= '7') {
+      bool octal = c == '0' || in_class ||
+                   (has(2) && peek(1) >= '0' && peek(1) <= '7' && peek(2) >= '0' && peek(2) <= '7');
+      if (!octal) return -1;
+      unsigned v = 0;
+      int nd = 0;
+      while (nd < 3 && !eof() && peek() >= '0' && peek() <= '7') {
+        v = v * 8 + (peek() - '0');
+        pos_++;
+        nd++;
+      }
+      if (v > 0xFF) throw CompileError("octal escape does not fit a byte");
+      return static_cast<int>(v);
+    }
+    bool alnum = (c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z');
+    if (!alnum) { pos_++; return c; }
+    return -1;
+  }
+
+  bool class_escape(ByteSet &out) {
+    if (eof()) return false;
+    ByteSet s;
+    bool neg = false;
+    switch (peek()) {
+      case 'd': s = cls_digit(); break;
+      case 'D': s = cls_digit(); neg = true; break;
+      case 'w': s = cls_word(); break;
+      case 'W': s = cls_word(); neg = true; break;
+      case 's': s = cls_space(); break;
+      case 'S': s = cls_space(); neg = true; break;
+      case 'h': s = cls_hspace(); break;
+      case 'H': s = cls_hspace(); neg = true; break;
+      case 'v': s = cls_vspace(); break;
+      case 'V': s = cls_vspace(); neg = true; break;
+      case 'N': s.set('\n'); neg = true; break;
+      default: return false;
+    }
+    pos_++;
+    out |= neg ? ~s : s;
+    return true;
+  }
+
+  static bool posix_set(const std::string &name, ByteSet &s) {
+    if (name == "alpha") { set_range(s, 'a', 'z'); set_range(s, 'A', 'Z'); }
+    else if (name == "digit") s |= cls_digit();
+    else if (name == "alnum") { set_range(s, 'a', 'z'); set_range(s, 'A', 'Z'); s |= cls_digit(); }
+    else if (name == "upper") set_range(s, 'A', 'Z');
+    else if (name == "lower") set_range(s, 'a', 'z');
+    else if (name == "space") s |= cls_space();
+    else if (name == "blank") { s.set(' '); s.set(9); }
+    else if (name == "punct") { for (int b = 33; b < 127; b++) if (!hg_is_word(b) || b == '_') s.set(b); }
+    else if (name == "print") set_range(s, 32, 126);
+    else if (name == "graph") set_range(s, 33, 126);
+    else if (name == "cntrl") { set_range(s, 0, 31); s.set(127); }
+    else if (name == "xdigit") { s |= cls_digit(); set_range(s, 'a', 'f'); set_range(s, 'A', 'F'); }
+    else if (name == "word") s |= cls_word();
+    else if (name == "ascii") set_range(s, 0, 127);
+    else return false;
+    return true;
+  }
+
+  NodeP bracket() {  // pos_ just past '['
+    ByteSet set;
+    bool neg = false;
+    if (!eof() && peek() == '^') { neg = true; pos_++; }
+    bool first = true;
+    for (;;) {
+      if (eof()) throw CompileError("unterminated character class");
+      unsigned char c = peek();
+      if (c == ']' && !first) { pos_++; break; }
+      first = false;
+      int lo;
+      if (c == '[' && has(1) && peek(1) == ':') {
+        size_t q = pos_ + 2;
+        bool pneg = false;
+        if (q < s_.size() && s_[q] == '^') { pneg = true; q++; }
+        size_t e = s_.find(":]", q);
+        if (e != std::string::npos) {
+          ByteSet ps;
+          if (!posix_set(s_.substr(q, e - q), ps)) throw CompileError("unknown POSIX class name");
+          set |= pneg ? ~ps : ps;
+          pos_ = e + 2;
+          continue;
+        }
+      }
+      if (c == '\\') {
+        pos_++;
+        if (eof()) throw CompileError("pattern ends inside a character class");
+        if (class_escape(set)) continue;
+        lo = byte_escape(true);
+        if (lo < 0) throw CompileError("unsupported escape in character class");
+      } else {
+        lo = c;
+        pos_++;
+      }
+      if (has(1) && peek() == '-' && peek(1) != ']') {
+        pos_++;
+        int hi;
+        if (peek() == '\\') {
+          pos_++;
+          ByteSet tmp;
+          if (class_escape(tmp)) {  // "a-\d": the '-' is a literal
+            set.set(lo);
+            set.set('-');
+            set |= tmp;
+            continue;
+          }
+          hi = byte_escape(true);
+          if (hi < 0) throw CompileError("unsupported escape in character class range");
+        } else if (peek() == '[' && has(1) && peek(1) == ':') {
+          throw CompileError("POSIX class used as a range endpoint");
+        } else {
+          hi = peek();
+          pos_++;
+        }
+        if (hi < lo) throw CompileError("range out of order in character class");
+        set_range(set, lo, hi);
+      } else {
+        set.set(lo);
+      }
+    }
+    if (caseless_) add_caseless(set);
+    if (neg) set = ~set;
+    if (set.none()) throw CompileError("character class matches nothing");
+    NodeP n = make(Node::Class);
+    n->cls = set;
+    return n;
+  }
+
+  NodeP assertion(uint32_t tt, bool start_anchor = false, bool end_anchor = false) {
+    NodeP n = make(Node::Assert);
+    n->tt = tt;
+    n->start_anchor = start_anchor;
+    n->end_anchor = end_anchor;
+    return n;
+  }
+
+  NodeP close_group(NodeP inner) {
+    if (eof() || peek() != ')') throw CompileError("missing closing parenthesis");
+    pos_++;
+    return inner;
+  }
+
+  // Returns zero or more atoms (zero: option-setting group or comment; several: a \Q..\E run).
+  std::vector<NodeP> atom() {
+    std::vector<NodeP> out;
+    unsigned char c = peek();
+    if (c == '(') {
+      pos_++;
+      if (++depth_ > 200) throw CompileError("pattern nesting too deep");
+      if (!eof() && peek() == '*') throw CompileError("backtracking control verbs are not supported");
+      if (!eof() && peek() == '?') {
+        pos_++;
+        group_extension(out);
+      } else {
+        FlagState f = save();
+        NodeP inner = alternation();
+        restore(f);
+        out.push_back(close_group(std::move(inner)));
+      }
+      depth_--;
+      return out;
+    }
+    if (c == '[') { pos_++; out.push_back(bracket()); return out; }
+    if (c == '.') {
+      pos_++;
+      NodeP n = make(Node::Class);
+      n->cls.set();
+      if (!dotall_) n->cls.reset('\n');
+      out.push_back(std::move(n));
+      return out;
+    }
+    if (c == '^') { pos_++; out.push_back(multiline_ ? assertion(TT_BOL_ML) : assertion(TT_BOL, true, false)); return out; }
+    if (c == '$') { pos_++; out.push_back(multiline_ ? assertion(TT_EOL_ML) : assertion(TT_EOL, false, true)); return out; }
+    if (c != '\\') { pos_++; out.push_back(byte_node(c)); return out; }
+    pos_++;
+    if (eof()) throw CompileError("pattern ends with a backslash");
+    unsigned char e = peek();
+    switch (e) {
+      case 'b': pos_++; out.push_back(assertion(TT_WB)); return out;
+      case 'B': pos_++; out.push_back(assertion(TT_NWB)); return out;
+      case 'A': pos_++; out.push_back(assertion(TT_BOL, true, false)); return out;
+      case 'Z': pos_++; out.push_back(assertion(TT_EOL, false, true)); return out;
+      case 'z': pos_++; out.push_back(assertion(TT_EOD, false, true)); return out;
+      case 'E': pos_++; return out;
+      case 'Q': {
+        pos_++;
+        while (!eof()) {
+          if (has(1) && peek() == '\\' && peek(1) == 'E') { pos_ += 2; break; }
+          out.push_back(byte_node(peek()));
+          pos_++;
+        }
+        return out;
+      }
+      case 'G': case 'K': case 'X': case 'R': case 'C':
+        throw CompileError(std::string("\\") + static_cast<char>(e) + " is not supported");
+      case 'p': case 'P': throw CompileError("unicode properties need UCP mode, which is not supported");
+      case 'g': case 'k': throw CompileError("back-references are not supported");
+      default: break;
+    }
+    ByteSet cs;
+    if (class_escape(cs)) {
+      NodeP n = make(Node::Class);
+      n->cls = cs;
+      if (caseless_) add_caseless(n->cls);
+      out.push_back(std::move(n));
+      return out;
+    }
+    int b = byte_escape(false);
+    if (b < 0) {
+      if (e >= '1' && e <= '9') throw CompileError("back-references are not supported");
+      throw CompileError(std::string("unsupported escape \\") + static_cast<char>(e));
+    }
+    out.push_back(byte_node(b));
+    return out;
+  }
+
+  void group_extension(std::vector<NodeP> &out) {  // pos_ just past "(?"
+    if (eof()) throw CompileError("unterminated group");
+    unsigned char c = peek();
+    auto scoped = [&]() {
+      FlagState f = save();
+      NodeP inner = alternation();
+      restore(f);
+      out.push_back(close_group(std::move(inner)));
+    };
+    if (c == '#') {
+      size_t e = s_.find(')', pos_);
+      if (e == std::string::npos) throw CompileError("unterminated comment");
+      pos_ = e + 1;
+      return;
+    }
+    if (c == ':') { pos_++; scoped(); return; }
+    if (c == '=' || c == '!') throw CompileError("lookahead assertions are not supported");
+    if (c == '>') throw CompileError("atomic groups are not supported");
+    if (c == '(') throw CompileError("conditional subpatterns are not supported");
+    if (c == 'R' || c == '&' || c == '+' || (c >= '0' && c <= '9')) throw CompileError("recursion and subroutine calls are not supported");
+    if (c == 'C') throw CompileError("callouts are not supported");
+    if (c == '|') throw CompileError("branch reset groups are not supported");
+    if (c == '<' || c == 'P' || c == '\'') {
+      size_t q = pos_;
+      char close = '>';
+      if (c == 'P') {
+        q++;
+        if (q < s_.size() && (s_[q] == '=' || s_[q] == '>')) throw CompileError("named back-references and recursion are not supported");
+        if (q >= s_.size() || s_[q] != '<') throw CompileError("malformed (?P group");
+        q++;
+      } else if (c == '<') {
+        q++;
+        if (q < s_.size() && (s_[q] == '=' || s_[q] == '!')) throw CompileError("lookbehind assertions are not supported");
+      } else {
+        q++;
+        close = '\'';
+      }
+      size_t start = q;
+      while (q < s_.size() && hg_is_word(static_cast<unsigned char>(s_[q]))) q++;
+      if (q == start || q >= s_.size() || s_[q] != close) throw CompileError("malformed group name");
+      pos_ = q + 1;
+      scoped();
+      return;
+    }
+    // inline options
+    bool on = true, any = false;
+    FlagState f = save();
+    while (!eof()) {
+      c = peek();
+      bool *target = nullptr;
+      if (c == 'i') target = &f.i;
+      else if (c == 's') target = &f.s;
+      else if (c == 'm') target = &f.m;
+      else if (c == 'x') target = &f.x;
+      else if (c == '-') { on = false; any = true; pos_++; continue; }
+      else break;
+      *target = on;
+      any = true;
+      pos_++;
+    }
+    if (!any || eof()) throw CompileError("unsupported group construct");
+    if (peek() == ')') {  // applies to the rest of the enclosing group
+      pos_++;
+      restore(f);
+      return;
+    }
+    if (peek() == ':') {
+      pos_++;
+      FlagState outer = save();
+      restore(f);
+      NodeP inner = alternation();
+      restore(outer);
+      out.push_back(close_group(std::move(inner)));
+      return;
+    }
+    throw CompileError("unsupported inline option");
+  }
+};
+
+// ---------------------------------------------------------------- static checks
+bool can_consume(const Node &n) {
+  switch (n.kind) {
+    case Node::Class: return true;
+    case Node::Cat: case Node::Alt:
+      for (auto &k : n.kids) if (can_consume(*k)) return true;
+      return false;
+    case Node::Rep: return n.max != 0 && can_consume(*n.kids[0]);
+    default: return false;
+  }
+}
+
+void check_embedded_anchors(const Node &n, bool before, bool after) {
+  switch (n.kind) {
+    case Node::Assert:
+      if (n.start_anchor && before) throw CompileError("embedded start anchors are not supported");
+      if (n.end_anchor && after) throw CompileError("embedded end anchors are not supported");
+      break;
+    case Node::Cat:
+      for (size_t i = 0; i < n.kids.size(); i++) {
+        bool b = before, a = after;
+        for (size_t j = 0; j < i; j++) b = b || can_consume(*n.kids[j]);
+        for (size_t j = i + 1; j < n.kids.size(); j++) a = a || can_consume(*n.kids[j]);
+        check_embedded_anchors(*n.kids[i], b, a);
+      }
+      break;
+    case Node::Alt:
+      for (auto &k : n.kids) check_embedded_anchors(*k, before, after);
+      break;
+    case Node::Rep: {
+      bool loops = (n.max < 0 || n.max > 1) && can_consume(*n.kids[0]);
+      check_embedded_anchors(*n.kids[0], before || loops, after || loops);
+      break;
+    }
+    default: break;
+  }
+}
+
+// ---------------------------------------------------------------- position automaton
+struct Cond { uint32_t pos, tt; };
+struct Frag {
+  uint32_t nullable = 0;  // contexts in which the fragment matches the empty string
+  std::vector<Cond> first, last;
+};
+
+class Glushkov {
+ public:
+  std::vector<ByteSet> pos_class;
+  std::map<std::pair<uint32_t, uint32_t>, uint32_t> edges;  // (p, q) -> tt
+
+  Frag build(const Node &n) {
+    switch (n.kind) {
+      case Node::Empty: { Frag f; f.nullable = HG_TT_ALL; return f; }
+      case Node::Assert: { Frag f; f.nullable = n.tt; return f; }
+      case Node::Class: {
+        if (pos_class.size() >= HG_MAX_NODES) throw CompileError("pattern too large");
+        uint32_t p = static_cast<uint32_t>(pos_class.size());
+        pos_class.push_back(n.cls);
+        Frag f;
+        f.first.push_back({p, HG_TT_ALL});
+        f.last.push_back({p, HG_TT_ALL});
+        return f;
+      }
+      case Node::Cat: {
+        Frag acc;
+        acc.nullable = HG_TT_ALL;
+        for (auto &k : n.kids) acc = cat(acc, build(*k));
+        return acc;
+      }
+      case Node::Alt: {
+        Frag acc = build(*n.kids[0]);
+        for (size_t i = 1; i < n.kids.size(); i++) acc = alt(acc, build(*n.kids[i]));
+        return acc;
+      }
+      case Node::Rep: {
+        const Node &k = *n.kids[0];
+        Frag acc;
+        acc.nullable = HG_TT_ALL;
+        for (int i = 0; i < n.min; i++) acc = cat(acc, build(k));
+        if (n.max < 0) {
+          Frag loop = build(k);
+          link(loop.last, loop.first);
+          loop.nullable = HG_TT_ALL;
+          acc = cat(acc, loop);
+        } else {
+          // k{0,m} as (k(k(k)?)?)? : linear number of edges
+          Frag tail;
+          tail.nullable = HG_TT_ALL;
+          for (int i = n.min; i < n.max; i++) {
+            tail = cat(build(k), tail);
+            tail.nullable = HG_TT_ALL;
+          }
+          acc = cat(acc, tail);
+        }
+        return acc;
+      }
+    }
+    return Frag();
+  }
+
+ private:
+  static void merge(std::vector<Cond> &dst, uint32_t pos, uint32_t tt) {
+    if (!tt) return;
+    for (auto &c : dst)
+      if (c.pos == pos) { c.tt |= tt; return; }
+    dst.push_back({pos, tt});
+  }
+  void link(const std::vector<Cond> &from, const std::vector<Cond> &to) {
+    for (auto &l : from)
+      for (auto &f : to) {
+        uint32_t tt = l.tt & f.tt;
+        if (tt) edges[{l.pos, f.pos}] |= tt;
+      }
+  }
+  Frag cat(const Frag &a, const Frag &b) {
+    Frag r;
+    link(a.last, b.first);
+    r.nullable = a.nullable & b.nullable;
+    r.first = a.first;
+    for (auto &f : b.first) merge(r.first, f.pos, f.tt & a.nullable);
+    r.last = b.last;
+    for (auto &l : a.last) merge(r.last, l.pos, l.tt & b.nullable);
+    return r;
+  }
+  static Frag alt(const Frag &a, const Frag &b) {
+    Frag r = a;
+    r.nullable |= b.nullable;
+    for (auto &f : b.first) merge(r.first, f.pos, f.tt);
+    for (auto &l : b.last) merge(r.last, l.pos, l.tt);
+    return r;
+  }
+};
+
+// ---------------------------------------------------------------- required-literal analysis
+struct Lit {
+  std::string bytes, cmask;  // cmask: 0xFF exact, 0xDF either case
+  bool operator<(const Lit &o) const { return std::tie(bytes, cmask) < std::tie(o.bytes, o.cmask); }
+  bool operator==(const Lit &o) const { return bytes == o.bytes && cmask == o.cmask; }
+};
+using LitSet = std::vector<Lit>;
+constexpr size_t MAX_EXACT = 16;      // strings in an exact set / cover
+constexpr size_t MAX_EXACT_LEN = 96;  // bytes per string while concatenating
+
+struct Info {
+  bool exact = false;  // language of the node is exactly `set`
+  LitSet set;
+  bool has_cover = false;  // every match contains one of `cover`
+  LitSet cover;
+};
+
+int byte_commonness(unsigned char b) {
+  if (b == ' ') return 10;
+  if (b >= 'a' && b <= 'z') return std::strchr("etaoinsrhl", b) ? 8 : 5;
+  if (b >= '0' && b <= '9') return 6;
+  if (std::strchr("=:-./_", b)) return 4;
+  if (b >= 'A' && b <= 'Z') return 2;
+  if (b > 32 && b < 127) return 2;
+  return 1;
+}
+int window_score(const Lit &l, size_t off) {
+  int s = 0;
+  for (size_t i = 0; i < 4; i++) s += byte_commonness(static_cast<unsigned char>(l.bytes[off + i]));
+  return s;
+}
+
+size_t min_len(const LitSet &s) {
+  size_t m = SIZE_MAX;
+  for (auto &l : s) m = std::min(m, l.bytes.size());
+  return s.empty() ? 0 : m;
+}
+void dedupe(LitSet &s) {
+  std::sort(s.begin(), s.end());
+  s.erase(std::unique(s.begin(), s.end()), s.end());
+}
+// Better cover: longer shortest literal (saturating at 16), then fewer literals, then longer.
+bool better_cover(const LitSet &a, const LitSet &b) {
+  size_t ma = std::min<size_t>(min_len(a), 16), mb = std::min<size_t>(min_len(b), 16);
+  if (ma != mb) return ma > mb;
+  if (a.size() != b.size()) return a.size() < b.size();
+  return min_len(a) > min_len(b);
+}
+void offer(Info &info, const LitSet &cand) {
+  if (cand.empty() || min_len(cand) == 0 || cand.size() > MAX_EXACT) return;
+  if (!info.has_cover || better_cover(cand, info.cover)) {
+    info.has_cover = true;
+    info.cover = cand;
+  }
+}
+bool cross(const LitSet &a, const LitSet &b, LitSet &out) {
+  if (a.size() * b.size() > MAX_EXACT) return false;
+  out.clear();
+  for (auto &x : a)
+    for (auto &y : b) {
+      if (x.bytes.size() + y.bytes.size() > MAX_EXACT_LEN) return false;
+      out.push_back({x.bytes + y.bytes, x.cmask + y.cmask});
+    }
+  dedupe(out);
+  return true;
+}
+
+Info analyze(const Node &n) {
+  Info r;
+  switch (n.kind) {
+    case Node::Empty: case Node::Assert:
+      r.exact = true;
+      r.set.push_back({"", ""});
+      return r;
+    case Node::Class: {
+      size_t cnt = n.cls.count();
+      ByteSet folded;
+      for (int b = 0; b < 256; b++) if (n.cls[b]) folded.set((b >= 'A' && b <= 'Z') ? b + 32 : b);
+      bool case_closed = true;
+      for (int b = 'a'; b <= 'z'; b++) if (n.cls[b] != n.cls[b - 32]) case_closed = false;
+      if (cnt <= 4 || (case_closed && folded.count() <= 4)) {
+        r.exact = true;
+        for (int b = 0; b < 256; b++) {
+          if (!n.cls[b]) continue;
+          if (b >= 'A' && b <= 'Z' && n.cls[b + 32]) continue;  // represented by the lower-case entry
+          bool both = b >= 'a' && b <= 'z' && n.cls[b - 32];
+          r.set.push_back({std::string(1, static_cast<char>(b)), std::string(1, static_cast<char>(both ? 0xDF : 0xFF))});
+        }
+      }
+      return r;
+    }
+    case Node::Cat: {
+      LitSet run{{"", ""}};
+      bool all_exact = true;
+      auto flush = [&]() {
+        offer(r, run);
+        run = LitSet{{"", ""}};
+      };
+      for (auto &k : n.kids) {
+        Info ki = analyze(*k);
+        if (ki.has_cover) offer(r, ki.cover);
+        if (ki.exact) {
+          LitSet next;
+          if (cross(run, ki.set, next)) run = std::move(next);
+          else { all_exact = false; flush(); run = ki.set; if (run.size() > MAX_EXACT) run = LitSet{{"", ""}}; }
+        } else {
+          all_exact = false;
+          flush();
+        }
+      }
+      if (all_exact) { r.exact = true; r.set = run; }
+      offer(r, run);
+      return r;
+    }
+    case Node::Alt: {
+      bool all_exact = true, all_cover = true;
+      LitSet uni, cov;
+      for (auto &k : n.kids) {
+        Info ki = analyze(*k);
+        if (ki.exact) { uni.insert(uni.end(), ki.set.begin(), ki.set.end()); }
+        else all_exact = false;
+        const LitSet *c = ki.has_cover ? &ki.cover : (ki.exact && min_len(ki.set) > 0 ? &ki.set : nullptr);
+        if (ki.exact && ki.has_cover && min_len(ki.set) > 0 && better_cover(ki.set, ki.cover)) c = &ki.set;
+        if (c) cov.insert(cov.end(), c->begin(), c->end());
+        else all_cover = false;
+      }
+      dedupe(uni);
+      dedupe(cov);
+      if (all_exact && uni.size() <= MAX_EXACT) { r.exact = true; r.set = uni; }
+      if (all_cover) offer(r, cov);
+      if (r.exact) offer(r, r.set);
+      return r;
+    }
+    case Node::Rep: {
+      Info ki = analyze(*n.kids[0]);
+      if (ki.exact && n.min == n.max && n.min <= 64) {
+        LitSet acc{{"", ""}};
+        bool ok = true;
+        for (int i = 0; i < n.min && ok; i++) {
+          LitSet next;
+          ok = cross(acc, ki.set, next);
+          if (ok) acc = std::move(next);
+        }
+        if (ok) { r.exact = true; r.set = acc; offer(r, acc); return r; }
+      }
+      if (n.min >= 1) {
+        if (ki.has_cover) offer(r, ki.cover);
+        if (ki.exact) {  // at least `min` consecutive copies are required
+          LitSet acc{{"", ""}};
+          for (int i = 0; i < std::min(n.min, 32); i++) {
+            LitSet next;
+            if (!cross(acc, ki.set, next)) break;
+            acc = std::move(next);
+          }
+          offer(r, acc);
+        }
+      }
+      return r;
+    }
+  }
+  return r;
+}
+
+// Keep at most HG_FACTOR_MAX bytes of a long literal: the sub-run whose rarest window is rarest.
+Lit clip(const Lit &l) {
+  if (l.bytes.size() <= HG_FACTOR_MAX) return l;
+  size_t best = 0;
+  int best_score = INT32_MAX;
+  for (size_t o = 0; o + HG_FACTOR_MAX <= l.bytes.size(); o++) {
+    int s = 0;
+    for (size_t i = 0; i < HG_FACTOR_MAX; i++) s += byte_commonness(static_cast<unsigned char>(l.bytes[o + i]));
+    if (s < best_score) { best_score = s; best = o; }
+  }
+  return {l.bytes.substr(best, HG_FACTOR_MAX), l.cmask.substr(best, HG_FACTOR_MAX)};
+}
+
+}  // namespace
+
+int hg_compile(const char *const *exprs, const unsigned *flags, const unsigned *ids, unsigned n, HgDb **out,
+               std::string *err, int *bad_index) {
+  if (bad_index) *bad_index = -1;
+  if (out) *out = nullptr;
+  if (!exprs || !out || n == 0) {
+    if (err) *err = "invalid arguments: at least one expression is required";
+    return -1;
+  }
+  auto db = std::make_unique<HgDb>();
+  struct Pending { std::vector<Lit> lits; bool caseless; };
+  std::vector<Pending> covers(n);
+  unsigned cur = 0;
+  try {
+    for (cur = 0; cur < n; cur++) {
+      uint32_t f = flags ? flags[cur] : 0;
+      if (f & ~HG_FLAGS_SUPPORTED) throw CompileError("unsupported flag bits");
+      if (!exprs[cur] || !exprs[cur][0]) throw CompileError("empty expression");
+      std::string text(exprs[cur]);
+      db->exprs.push_back(text);
+      Parser parser(text, f);
+      NodeP root = parser.parse();
+      check_embedded_anchors(*root, false, false);
+
+      Glushkov g;
+      Frag top = g.build(*root);
+      if (top.nullable) throw CompileError("expression can match the empty string (HS_FLAG_ALLOWEMPTY is not supported)");
+      if (g.pos_class.empty()) throw CompileError("expression matches nothing");
+
+      // nodes = distinct (position, entry condition)
+      std::map<std::pair<uint32_t, uint32_t>, uint32_t> node_id;
+      std::vector<std::pair<uint32_t, uint32_t>> nodes;
+      auto intern = [&](uint32_t pos, uint32_t tt) {
+        auto key = std::make_pair(pos, tt);
+        auto it = node_id.find(key);
+        if (it != node_id.end()) return it->second;
+        uint32_t id = static_cast<uint32_t>(nodes.size());
+        node_id.emplace(key, id);
+        nodes.push_back(key);
+        return id;
+      };
+      // order nodes by position so that linear expressions get follow = next bit
+      std::vector<std::pair<uint32_t, uint32_t>> wanted;
+      for (auto &c : top.first) wanted.push_back({c.pos, c.tt});
+      for (auto &e : g.edges) wanted.push_back({e.first.second, e.second});
+      std::sort(wanted.begin(), wanted.end());
+      wanted.erase(std::unique(wanted.begin(), wanted.end()), wanted.end());
+      for (auto &w : wanted) intern(w.first, w.second);
+      if (nodes.size() > HG_MAX_NODES) throw CompileError("pattern too large");
+
+      uint32_t nn = static_cast<uint32_t>(nodes.size()), nw = (nn + 31) / 32;
+      HgPattern p{};
+      p.id = ids ? ids[cur] : 0;
+      p.flags = f;
+      p.nnodes = nn;
+      p.nw = nw;
+      p.single = (f & HG_FLAG_SINGLEMATCH) ? 1 : 0;
+      auto alloc = [&](size_t words) {
+        uint32_t off = static_cast<uint32_t>(db->pool.size());
+        db->pool.resize(db->pool.size() + words, 0);
+        return off;
+      };
+      p.reach_off = alloc(256 * nw);
+      p.follow_off = alloc(static_cast<size_t>(nn) * nw);
+      p.init_off = alloc(nw);
+      p.amask_off = alloc(16 * nw);
+      p.acc_off = alloc(20 * nw);
+      std::vector<uint32_t> last_tt(g.pos_class.size(), 0);
+      for (auto &l : top.last) last_tt[l.pos] |= l.tt;
+      auto setbit = [&](uint32_t base, uint32_t node) { db->pool[base + node / 32] |= 1u << (node % 32); };
+      for (uint32_t v = 0; v < nn; v++) {
+        uint32_t pos = nodes[v].first, tt = nodes[v].second;
+        for (int b = 0; b < 256; b++)
+          if (g.pos_class[pos][b]) setbit(p.reach_off + b * nw, v);
+        for (uint32_t pc = 0; pc < 4; pc++) {
+          for (uint32_t cc = 0; cc < 4; cc++)
+            if (tt >> (pc * 5 + cc) & 1) setbit(p.amask_off + (pc * 4 + cc) * nw, v);
+          for (uint32_t nc = 0; nc < 5; nc++)
+            if (last_tt[pos] >> (pc * 5 + nc) & 1) setbit(p.acc_off + (pc * 5 + nc) * nw, v);
+        }
+      }
+      for (auto &c : top.first) setbit(p.init_off, intern(c.pos, c.tt));
+      std::vector<std::vector<uint32_t>> nodes_of(g.pos_class.size());
+      for (uint32_t v = 0; v < nn; v++) nodes_of[nodes[v].first].push_back(v);
+      for (auto &e : g.edges) {
+        uint32_t to = intern(e.first.second, e.second);
+        for (uint32_t v : nodes_of[e.first.first]) setbit(p.follow_off + v * nw, to);
+      }
+      db->max_nw = std::max(db->max_nw, nw);
+
+      // required literals
+      Info info = analyze(*root);
+      LitSet cover;
+      if (info.has_cover) for (auto &l : info.cover) cover.push_back(clip(l));
+      dedupe(cover);
+      bool fast = !cover.empty() && min_len(cover) >= HG_FAST_MIN_FACTOR;
+      // a literal containing '\n' before its last byte can never lie inside one line; keep such patterns always-on
+      p.tier = fast ? 0 : 1;
+      if (fast) {
+        covers[cur].lits = cover;
+        for (auto &l : cover)
+          for (unsigned char m : l.cmask)
+            if (m != 0xFF) db->fold_mask = 0x20202020u;
+      } else {
+        db->slow.push_back(cur);
+      }
+      db->patterns.push_back(p);
+    }
+  } catch (const CompileError &e) {
+    if (err) *err = e.what();
+    if (bad_index) *bad_index = static_cast<int>(cur);
+    return -4;
+  } catch (const std::bad_alloc &) {
+    if (err) *err = "out of memory";
+    if (bad_index) *bad_index = static_cast<int>(cur);
+    return -2;
+  }
+
+  // factors + windows (needs the final fold mask)
+  std::vector<std::pair<uint32_t, HgWindow>> keyed;
+  for (unsigned i = 0; i < n; i++) {
+    for (auto &l : covers[i].lits) {
+      HgFactor fct{};
+      fct.pattern = i;
+      fct.len = static_cast<uint32_t>(l.bytes.size());
+      std::memcpy(fct.lit, l.bytes.data(), fct.len);
+      std::memcpy(fct.cmask, l.cmask.data(), fct.len);
+      uint32_t fi = static_cast<uint32_t>(db->factors.size());
+      db->factors.push_back(fct);
+      for (uint32_t res = 0; res < 4; res++) {
+        int best = -1, best_score = INT32_MAX;
+        for (uint32_t o = res; o + 4 <= fct.len; o += 4) {
+          int s = window_score(l, o);
+          if (s < best_score) { best_score = s; best = static_cast<int>(o); }
+        }
+        if (best < 0) continue;  // cannot happen for len >= 7
+        uint32_t v;
+        std::memcpy(&v, fct.lit + best, 4);
+        // case-insensitive positions hold lower-case letters already; folding maps both cases onto them
+        v |= db->fold_mask;
+        HgWindow w{v, (fi << 8) | static_cast<uint32_t>(best)};
+        keyed.push_back({hg_hash_window(v), w});
+      }
+    }
+  }
+  std::stable_sort(keyed.begin(), keyed.end(), [](auto &a, auto &b) { return a.first < b.first; });
+  db->bucket_off.assign((1u << HG_HASH_BITS) + 1, 0);
+  db->bitmap.assign(HG_BITMAP_WORDS, 0);
+  for (auto &kw : keyed) {
+    db->bucket_off[kw.first + 1]++;
+    db->bitmap[kw.first >> 5] |= 1u << (kw.first & 31);
+    db->windows.push_back(kw.second);
+  }
+  for (size_t i = 1; i < db->bucket_off.size(); i++) db->bucket_off[i] += db->bucket_off[i - 1];
+  if (db->windows.empty()) db->windows.push_back(HgWindow{0, 0});  // keep device arrays non-empty
+  if (db->factors.empty()) db->factors.push_back(HgFactor{});
+  *out = db.release();
+  return 0;
+}
+
+void hg_db_free(HgDb *db) { delete db; }

@@ -1,0 +1,26 @@
+// Host-side pattern compiler: the product's counterpart of hs_compile_multi
+// (reference call site hypergrep/lib/c/hyperscanner.c:136, mode HS_MODE_BLOCK, platform NULL).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "hg_db.h"
+
+struct HgDb {
+  std::vector<HgPattern> patterns;
+  std::vector<uint32_t> pool;        // all automaton tables
+  std::vector<HgFactor> factors;     // required literals of tier-0 patterns
+  std::vector<HgWindow> windows;     // grouped by bucket
+  std::vector<uint32_t> bucket_off;  // (1 << HG_HASH_BITS) + 1 offsets into windows
+  std::vector<uint32_t> bitmap;      // HG_BITMAP_WORDS: bucket non-empty bits (staged in LDS by the stream kernel)
+  std::vector<uint32_t> slow;        // indices of tier-1 (always-on) patterns
+  uint32_t fold_mask = 0;            // 0x20202020 when any tier-0 pattern is case-insensitive
+  uint32_t max_nw = 1;
+  std::vector<std::string> exprs;
+};
+
+// Returns 0 on success.  On failure returns non-zero, sets *err and *bad_index (expression index or -1).
+int hg_compile(const char *const *exprs, const unsigned *flags, const unsigned *ids, unsigned n, HgDb **out,
+               std::string *err, int *bad_index);
+void hg_db_free(HgDb *db);

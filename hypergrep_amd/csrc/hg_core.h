@@ -1,0 +1,236 @@
+// Scalar building blocks shared by the gfx950 kernels (hg_kernels.hip) and the host-side unit
+// tests (tests/native/hostsim.cpp compiles this header for x86 to exercise the exact same code).
+// Nothing here is a CPU scan path of the product: the shipped library only calls these from device code.
+//
+// Line / piece rules restated from hypergrep/lib/c/hyperscanner.c:198-226 (gzgets pieces of at most
+// buffer_size-1 bytes ending after '\n'; leading NULs skipped :207-214; scan stops at the first NUL
+// because the shim passes strlen() :217; line_number is the 0-based piece index :225).
+#pragma once
+#include "hg_db.h"
+
+constexpr uint32_t HG_TILE_BYTES = 16384;  // bytes one wavefront streams per tile (64 lanes x 16 B x 16 iterations)
+constexpr uint32_t HG_TILE_SHIFT = 14;
+constexpr uint32_t HG_NONE32 = 0xFFFFFFFFu;
+
+// Newline summary of one tile, written by the stream kernel.
+struct HgTileSum {
+  uint32_t nl_count;  // '\n' bytes in the tile
+  uint32_t first_nl;  // tile-relative offset of the first / last '\n' (HG_NONE32 if none)
+  uint32_t last_nl;
+  uint32_t pad;
+};
+// Prefix state at the start of a tile, written by the tile-scan kernel.
+struct HgTileBase {
+  uint64_t cs;  // absolute start of the line that is open at the tile start ("carry-in" line)
+  uint64_t L;   // piece index (= reference line_number) of the piece starting at cs
+};
+// A verified required-literal occurrence: pattern `pattern` may match in the line containing byte `pos`.
+struct HgCand {
+  uint64_t pos;
+  uint32_t pattern;
+  uint32_t rank;  // '\n' bytes in [tile start, pos)
+};
+// Final records (16 B + 16 B): one per (line piece, report).
+struct HgHit {
+  uint64_t line_no;  // 0-based piece index: hyperscanner_result_t.line_number
+  uint32_t id;       // hyperscanner_result_t.id
+  uint32_t to;       // match end offset inside the scanned bytes (Hyperscan's `to`)
+};
+struct HgHitAux {
+  uint64_t start;  // absolute offset of the bytes Result.line holds
+  uint32_t len;
+  uint32_t pattern;
+};
+
+struct HgDbView {
+  const HgPattern *patterns;
+  const uint32_t *pool;
+  const HgFactor *factors;
+  const HgWindow *windows;
+  const uint32_t *bucket_off;
+  const uint32_t *slow;
+  uint32_t npatterns, nslow, fold_mask, pad;
+};
+
+// 0x80 in every byte of x that is zero, exact (no borrow between bytes).
+HG_HD uint32_t hg_zero_bytes(uint32_t x) {
+  uint32_t y = ((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x;
+  return ~y & 0x80808080u;
+}
+HG_HD uint32_t hg_newline_mask(uint32_t w) { return hg_zero_bytes(w ^ 0x0a0a0a0au); }
+
+HG_HD uint32_t hg_popc(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __popc(x);
+#else
+  return static_cast<uint32_t>(__builtin_popcount(x));
+#endif
+}
+HG_HD uint32_t hg_ctz(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __ffs(x) - 1;
+#else
+  return static_cast<uint32_t>(__builtin_ctz(x));
+#endif
+}
+
+HG_HD uint32_t hg_prev_ctx(uint32_t c) { return c == '\n' ? HG_PC_NL : (hg_is_word(c) ? HG_PC_WORD : HG_PC_OTHER); }
+
+// Bucket probe + literal verify for one window hit at absolute byte `pos` (dword aligned) holding raw
+// dword `w`.  Calls emit(pattern) for every factor whose literal really occurs around pos.
+template <typename Emit>
+HG_HD void hg_verify_window(const HgDbView &db, const uint8_t *text, uint64_t nbytes, uint64_t pos, uint32_t w,
+                            Emit &&emit) {
+  uint32_t folded = w | db.fold_mask;
+  uint32_t h = hg_hash_window(folded);
+  for (uint32_t j = db.bucket_off[h], e = db.bucket_off[h + 1]; j < e; j++) {
+    HgWindow win = db.windows[j];
+    if (win.value != folded) continue;
+    uint32_t off = win.factor_off & 0xff;
+    const HgFactor &f = db.factors[win.factor_off >> 8];
+    if (pos < off) continue;
+    uint64_t start = pos - off;
+    if (start + f.len > nbytes) continue;
+    bool ok = true;
+    for (uint32_t b = 0; b < f.len; b++) {
+      if ((text[start + b] ^ f.lit[b]) & f.cmask[b]) { ok = false; break; }
+    }
+    if (ok) emit(f.pattern);
+  }
+}
+
+// Pieces of the carry-in line of a tile: ceil(len / bs1), len >= 1.
+HG_HD uint64_t hg_pieces(uint64_t len, uint64_t bs1) { return (len + bs1 - 1) / bs1; }
+
+// Piece index of the line that starts at a position with `rank` newlines before it in tile `t`
+// (rank == 0: the carry-in line itself).  Requires bs1 >= HG_TILE_BYTES so that lines lying inside one
+// tile are single pieces.
+HG_HD uint64_t hg_line_index(const HgTileSum &ts, const HgTileBase &tb, uint64_t tile_start, uint32_t rank, uint64_t bs1) {
+  if (rank == 0) return tb.L;
+  uint64_t carry_len = tile_start + ts.first_nl + 1 - tb.cs;
+  return tb.L + hg_pieces(carry_len, bs1) + (rank - 1);
+}
+
+// Bytes hs_scan would see for the piece [ps, limit): skip leading NULs, cut at the first NUL or after the
+// first '\n'.  Returns [a, z).
+HG_HD void hg_trim_piece(const uint8_t *text, uint64_t ps, uint64_t limit, uint64_t &a, uint64_t &z) {
+  a = ps;
+  while (a < limit && text[a] == 0) a++;
+  z = a;
+  while (z < limit) {
+    uint32_t c = text[z];
+    if (c == 0) break;
+    z++;
+    if (c == '\n') break;
+  }
+}
+
+// Run one pattern's automaton over data[0, len) (one trimmed piece).  emit(to) per distinct match end
+// offset in ascending order; returns after the first when `single`.
+template <typename Emit>
+HG_HD void hg_nfa_scan(const uint32_t *pool, const HgPattern &p, const uint8_t *data, uint64_t len, Emit &&emit) {
+  const uint32_t nw = p.nw;
+  const uint32_t *reach = pool + p.reach_off, *follow = pool + p.follow_off, *init = pool + p.init_off;
+  const uint32_t *amask = pool + p.amask_off, *acc = pool + p.acc_off;
+  const bool single = p.single != 0;
+  uint32_t pc = HG_PC_START;
+  if (nw == 1) {
+    uint32_t S = 0;
+    const uint32_t init0 = init[0];
+    for (uint64_t i = 0; i < len; i++) {
+      uint32_t c = data[i];
+      uint32_t cc = c == '\n' ? (i + 1 == len ? HG_NC_NLFINAL : HG_NC_NL) : (hg_is_word(c) ? HG_NC_WORD : HG_NC_OTHER);
+      if (S & acc[pc * 5 + cc]) {
+        emit(static_cast<uint32_t>(i));
+        if (single) return;
+      }
+      uint32_t T = init0;
+      for (uint32_t x = S; x; x &= x - 1) T |= follow[hg_ctz(x)];
+      S = T & reach[c] & amask[pc * 4 + cc];
+      pc = hg_prev_ctx(c);
+    }
+    if (S & acc[pc * 5 + HG_NC_END]) emit(static_cast<uint32_t>(len));
+    return;
+  }
+  uint32_t S[HG_MAX_W], T[HG_MAX_W];
+  for (uint32_t w = 0; w < nw; w++) S[w] = 0;
+  for (uint64_t i = 0; i < len; i++) {
+    uint32_t c = data[i];
+    uint32_t cc = c == '\n' ? (i + 1 == len ? HG_NC_NLFINAL : HG_NC_NL) : (hg_is_word(c) ? HG_NC_WORD : HG_NC_OTHER);
+    const uint32_t *a = acc + (pc * 5 + cc) * nw;
+    uint32_t any = 0;
+    for (uint32_t w = 0; w < nw; w++) any |= S[w] & a[w];
+    if (any) {
+      emit(static_cast<uint32_t>(i));
+      if (single) return;
+    }
+    for (uint32_t w = 0; w < nw; w++) T[w] = init[w];
+    for (uint32_t w = 0; w < nw; w++)
+      for (uint32_t x = S[w]; x; x &= x - 1) {
+        const uint32_t *f = follow + (w * 32 + hg_ctz(x)) * nw;
+        for (uint32_t k = 0; k < nw; k++) T[k] |= f[k];
+      }
+    const uint32_t *r = reach + c * nw, *m = amask + (pc * 4 + cc) * nw;
+    for (uint32_t w = 0; w < nw; w++) S[w] = T[w] & r[w] & m[w];
+    pc = hg_prev_ctx(c);
+  }
+  const uint32_t *a = acc + (pc * 5 + HG_NC_END) * nw;
+  uint32_t any = 0;
+  for (uint32_t w = 0; w < nw; w++) any |= S[w] & a[w];
+  if (any) emit(static_cast<uint32_t>(len));
+}
+
+// Confirm one candidate: locate the piece containing byte `pos`, trim it, run the pattern.
+// emit(line_no, to, a, len) per report.
+template <typename Emit>
+HG_HD void hg_confirm(const HgDbView &db, const uint8_t *text, uint64_t nbytes, const HgTileSum *sums,
+                      const HgTileBase *bases, uint64_t bs1, uint64_t pos, uint32_t pattern, uint32_t rank, Emit &&emit) {
+  uint64_t t = pos >> HG_TILE_SHIFT, tile_start = t << HG_TILE_SHIFT;
+  uint64_t s;
+  if (rank == 0) {
+    s = bases[t].cs;
+  } else {
+    s = pos;  // the previous '\n' lies inside this tile
+    while (s > tile_start && text[s - 1] != '\n') s--;
+  }
+  uint64_t k = (pos - s) / bs1;
+  uint64_t ps = s + k * bs1;
+  uint64_t line_no = hg_line_index(sums[t], bases[t], tile_start, rank, bs1) + k;
+  uint64_t limit = ps + bs1 < nbytes ? ps + bs1 : nbytes;
+  uint64_t a, z;
+  hg_trim_piece(text, ps, limit, a, z);
+  if (z <= a) return;
+  const HgPattern &p = db.patterns[pattern];
+  hg_nfa_scan(db.pool, p, text + a, z - a, [&](uint32_t to) { emit(line_no, to, a, static_cast<uint32_t>(z - a)); });
+}
+
+// Always-on tier: process every piece of the line that starts at absolute offset `s` (which has `rank`
+// newlines before it in its tile) with every tier-1 pattern.  emit(pattern, line_no, to, a, len).
+template <typename Emit>
+HG_HD void hg_scan_line_always_on(const HgDbView &db, const uint8_t *text, uint64_t nbytes, const HgTileSum *sums,
+                                  const HgTileBase *bases, uint64_t bs1, uint64_t s, uint32_t rank, Emit &&emit) {
+  uint64_t t = s >> HG_TILE_SHIFT, tile_start = t << HG_TILE_SHIFT;
+  uint64_t line_no = hg_line_index(sums[t], bases[t], tile_start, rank, bs1);
+  uint64_t ps = s;
+  for (;;) {
+    uint64_t limit = ps + bs1 < nbytes ? ps + bs1 : nbytes;
+    uint64_t a, z;
+    hg_trim_piece(text, ps, limit, a, z);
+    if (z > a) {
+      for (uint32_t j = 0; j < db.nslow; j++) {
+        uint32_t pi = db.slow[j];
+        hg_nfa_scan(db.pool, db.patterns[pi], text + a, z - a,
+                    [&](uint32_t to) { emit(pi, line_no, to, a, static_cast<uint32_t>(z - a)); });
+      }
+    }
+    // where does the piece end?  after its '\n', else at limit
+    uint64_t e = ps;
+    bool nl = false;
+    while (e < limit) {
+      if (text[e++] == '\n') { nl = true; break; }
+    }
+    if (nl || e >= nbytes) return;
+    ps = e;  // forced break: the line continues as the next piece
+    line_no++;
+  }
+}

@@ -1,0 +1,79 @@
+// Compiled pattern database layout shared by the host compiler and the gfx950 kernels.
+//
+// Replaces what hs_compile_multi builds for the reference (hypergrep/lib/c/hyperscanner.c:126-142):
+// instead of Hyperscan's opaque bytecode the database is a set of flat arrays that the engine uploads
+// to HBM once; the 32 KiB window bitmap is the only part staged in LDS by the streaming kernel.
+#pragma once
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define HG_HD __host__ __device__ __forceinline__
+#else
+#define HG_HD inline
+#endif
+
+// Flag values (hypergrep/utils.py:10-13).
+constexpr uint32_t HG_FLAG_CASELESS = 1, HG_FLAG_DOTALL = 2, HG_FLAG_MULTILINE = 4, HG_FLAG_SINGLEMATCH = 8;
+constexpr uint32_t HG_FLAGS_SUPPORTED = 15;
+
+// Boundary contexts for zero-width assertions.  Every assertion the compiler accepts (^ $ \A \z \Z \b \B)
+// is a boolean function of (context of the previous byte, context of the next byte); a 20-bit truth
+// table indexed [prev * 5 + next] represents any conjunction / disjunction of them exactly.
+enum : uint32_t { HG_PC_START = 0, HG_PC_NL = 1, HG_PC_WORD = 2, HG_PC_OTHER = 3 };                      // previous byte
+enum : uint32_t { HG_NC_NL = 0, HG_NC_NLFINAL = 1, HG_NC_WORD = 2, HG_NC_OTHER = 3, HG_NC_END = 4 };     // next byte
+constexpr uint32_t HG_TT_ALL = (1u << 20) - 1;
+
+constexpr uint32_t HG_MAX_NODES = 1024;  // per pattern (32 state words)
+constexpr uint32_t HG_MAX_W = HG_MAX_NODES / 32;
+constexpr uint32_t HG_FACTOR_MAX = 32;   // bytes of a required literal kept for the in-stream verify
+constexpr uint32_t HG_FAST_MIN_FACTOR = 7;  // 4-byte window on every residue mod 4 needs length >= 7
+constexpr uint32_t HG_HASH_BITS = 18;       // v_dot4_u32_u8 of four bytes with weights < 256 fits 18 bits
+constexpr uint32_t HG_BITMAP_WORDS = (1u << HG_HASH_BITS) / 32;  // 8192 words = 32 KiB of LDS
+constexpr uint32_t HG_HASH_WEIGHTS = 0xfbf1efe9u;  // byte weights 233, 239, 241, 251 (distinct primes)
+
+// One compiled expression: a position (Glushkov) automaton whose nodes are (position, entry condition).
+// Tables live in one u32 pool; *_off are indices into it.
+struct HgPattern {
+  uint32_t id;          // report id given by the caller
+  uint32_t flags;       // HS_FLAG_* bits
+  uint32_t nnodes;      // automaton nodes
+  uint32_t nw;          // state words = ceil(nnodes / 32)
+  uint32_t reach_off;   // reach[256][nw]   nodes whose byte class contains c
+  uint32_t follow_off;  // follow[nnodes][nw]
+  uint32_t init_off;    // init[nw]         nodes enterable from the (always active) start state
+  uint32_t amask_off;   // amask[4][4][nw]  nodes whose entry condition holds for (prev ctx, ctx of own byte)
+  uint32_t acc_off;     // acc[4][5][nw]    nodes that accept for (ctx of own byte, next ctx)
+  uint32_t tier;        // 0: anchored by a required literal (stream prefilter + confirm); 1: always-on
+  uint32_t single;      // HS_FLAG_SINGLEMATCH set
+  uint32_t pad[5];
+};
+static_assert(sizeof(HgPattern) == 64, "HgPattern layout");
+
+// A required literal of one pattern ("factor"): any match of the pattern contains an occurrence.
+struct HgFactor {
+  uint32_t pattern;              // index into patterns[]
+  uint32_t len;                  // <= HG_FACTOR_MAX
+  uint32_t pad[2];
+  uint8_t lit[HG_FACTOR_MAX];    // literal bytes
+  uint8_t cmask[HG_FACTOR_MAX];  // 0xFF exact, 0xDF case-insensitive letter
+};
+static_assert(sizeof(HgFactor) == 80, "HgFactor layout");
+
+// One 4-byte window of a factor, placed at literal offset `off`; keyed by the (folded) dword value.
+struct HgWindow {
+  uint32_t value;
+  uint32_t factor_off;  // factor index << 8 | off
+};
+
+HG_HD uint32_t hg_hash_window(uint32_t folded) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_udot4(folded, HG_HASH_WEIGHTS, 0u, false);
+#else
+  return (folded & 0xff) * (HG_HASH_WEIGHTS & 0xff) + ((folded >> 8) & 0xff) * ((HG_HASH_WEIGHTS >> 8) & 0xff) +
+         ((folded >> 16) & 0xff) * ((HG_HASH_WEIGHTS >> 16) & 0xff) + (folded >> 24) * (HG_HASH_WEIGHTS >> 24);
+#endif
+}
+
+HG_HD bool hg_is_word(uint32_t b) {
+  return (b - '0' < 10u) || ((b | 0x20) - 'a' < 26u) || b == '_';
+}

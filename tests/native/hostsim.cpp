@@ -1,0 +1,176 @@
+// TEST-ONLY host harness (never shipped, never loaded by the product): compiles the product's pattern
+// compiler and hg_core.h for x86 and replays the GPU pipeline's stages in scalar form —
+//   stream pass (newline summaries + window bitmap + literal verify)  ~ hg_stream_kernel
+//   tile scan                                                          ~ hg_tile_scan_*
+//   confirm / always-on                                                ~ hg_confirm_kernel / hg_always_on_kernel
+//   order + dedupe                                                     ~ hg_finalize
+// so the compiler's tables and the shared device logic can be checked against the oracle without a GPU.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../hypergrep_amd/csrc/hg_compile.h"
+#include "../../hypergrep_amd/csrc/hg_core.h"
+#include "../../hypergrep_amd/csrc/hg_post.h"
+
+extern "C" {
+
+struct SimHit {
+  uint64_t line_no;
+  uint32_t id, to;
+  uint64_t start;
+  uint32_t len, pattern;
+};
+
+void *hgsim_compile(const char *const *exprs, const unsigned *flags, const unsigned *ids, unsigned n, char *err, size_t errlen) {
+  HgDb *db = nullptr;
+  std::string e;
+  int bad = -1;
+  if (hg_compile(exprs, flags, ids, n, &db, &e, &bad) != 0) {
+    if (err && errlen) snprintf(err, errlen, "%d: %s", bad, e.c_str());
+    return nullptr;
+  }
+  return db;
+}
+void hgsim_free(void *h) { hg_db_free(static_cast<HgDb *>(h)); }
+
+void hgsim_info(void *h, uint32_t *out) {  // npatterns, nfactors, nwindows, nslow, fold_mask, max_nw
+  HgDb *db = static_cast<HgDb *>(h);
+  out[0] = db->patterns.size();
+  out[1] = db->factors.size();
+  out[2] = db->windows.size();
+  out[3] = db->slow.size();
+  out[4] = db->fold_mask;
+  out[5] = db->max_nw;
+}
+uint32_t hgsim_pattern_tier(void *h, uint32_t i) { return static_cast<HgDb *>(h)->patterns[i].tier; }
+uint32_t hgsim_pattern_nodes(void *h, uint32_t i) { return static_cast<HgDb *>(h)->patterns[i].nnodes; }
+
+// Run one pattern's automaton over one already-trimmed piece; returns number of reports, fills tos[<=cap].
+size_t hgsim_nfa(void *h, uint32_t pattern, const uint8_t *data, size_t len, uint32_t *tos, size_t cap) {
+  HgDb *db = static_cast<HgDb *>(h);
+  size_t n = 0;
+  hg_nfa_scan(db->pool.data(), db->patterns[pattern], data, len, [&](uint32_t to) {
+    if (n < cap) tos[n] = to;
+    n++;
+  });
+  return n;
+}
+
+static HgDbView view_of(HgDb *db) {
+  HgDbView v{};
+  v.patterns = db->patterns.data();
+  v.pool = db->pool.data();
+  v.factors = db->factors.data();
+  v.windows = db->windows.data();
+  v.bucket_off = db->bucket_off.data();
+  v.slow = db->slow.data();
+  v.npatterns = db->patterns.size();
+  v.nslow = db->slow.size();
+  v.fold_mask = db->fold_mask;
+  return v;
+}
+
+// Whole pipeline on a memory buffer.  Returns number of hits (after dedupe); *out is malloc'ed.
+// stats[0] = window bitmap hits, stats[1] = verified candidates, stats[2] = raw hits before dedupe, stats[3] = pieces
+long hgsim_scan(void *h, const uint8_t *data, uint64_t nbytes, int buffer_size, SimHit **out, uint64_t *stats) {
+  HgDb *db = static_cast<HgDb *>(h);
+  HgDbView v = view_of(db);
+  if (buffer_size < 2) { *out = nullptr; return 0; }
+  uint64_t bs1 = static_cast<uint64_t>(buffer_size) - 1;
+  if (bs1 < HG_TILE_BYTES) return -2;  // small-buffer mode is a separate path
+  uint64_t ntiles = (nbytes + HG_TILE_BYTES - 1) / HG_TILE_BYTES;
+  std::vector<HgTileSum> sums(ntiles ? ntiles : 1);
+  std::vector<HgTileBase> bases(ntiles + 1);
+  std::vector<HgCand> cands;
+  uint64_t bitmap_hits = 0;
+  // ---- stream pass
+  for (uint64_t t = 0; t < ntiles; t++) {
+    uint64_t base = t * HG_TILE_BYTES;
+    HgTileSum s{0, HG_NONE32, HG_NONE32, 0};
+    for (uint32_t d = 0; d < HG_TILE_BYTES / 4; d++) {
+      uint64_t pos = base + d * 4ull;
+      if (pos >= nbytes) break;
+      uint32_t w = 0;
+      uint64_t avail = nbytes - pos < 4 ? nbytes - pos : 4;
+      std::memcpy(&w, data + pos, avail);  // bytes past the end read as zero, as the kernel masks them
+      uint32_t rank_here = s.nl_count;
+      uint32_t m = hg_newline_mask(w);
+      if (m) {
+        for (uint32_t b = 0; b < 4; b++)
+          if (m >> (8 * b + 7) & 1) {
+            if (s.first_nl == HG_NONE32) s.first_nl = d * 4 + b;
+            s.last_nl = d * 4 + b;
+          }
+        s.nl_count += hg_popc(m);
+      }
+      uint32_t hsh = hg_hash_window(w | v.fold_mask);
+      if (db->bitmap[hsh >> 5] >> (hsh & 31) & 1) {
+        bitmap_hits++;
+        hg_verify_window(v, data, nbytes, pos, w, [&](uint32_t pattern) { cands.push_back(HgCand{pos, pattern, rank_here}); });
+      }
+    }
+    sums[t] = s;
+  }
+  // ---- tile scan
+  HgTileBase st{0, 0};
+  for (uint64_t t = 0; t < ntiles; t++) {
+    bases[t] = st;
+    st = hg_tile_apply(st, hg_tile_elem(sums[t], t * HG_TILE_BYTES), bs1);
+  }
+  bases[ntiles] = st;
+  uint64_t pieces = st.L + (nbytes > st.cs ? hg_pieces(nbytes - st.cs, bs1) : 0);
+  // ---- confirm
+  std::vector<HgHit> hits;
+  std::vector<HgHitAux> aux;
+  for (auto &c : cands) {
+    hg_confirm(v, data, nbytes, sums.data(), bases.data(), bs1, c.pos, c.pattern, c.rank,
+               [&](uint64_t line_no, uint32_t to, uint64_t a, uint32_t len) {
+                 hits.push_back(HgHit{line_no, db->patterns[c.pattern].id, to});
+                 aux.push_back(HgHitAux{a, len, c.pattern});
+               });
+  }
+  // ---- always-on tier: every line start
+  if (v.nslow) {
+    for (uint64_t t = 0; t < ntiles; t++) {
+      uint64_t base = t * HG_TILE_BYTES, end = std::min<uint64_t>(base + HG_TILE_BYTES, nbytes);
+      uint32_t rank = 0;
+      for (uint64_t s = base; s < end; s++) {
+        bool starts = (s == 0) || data[s - 1] == '\n';
+        if (starts)
+          hg_scan_line_always_on(v, data, nbytes, sums.data(), bases.data(), bs1, s, rank,
+                                 [&](uint32_t pi, uint64_t line_no, uint32_t to, uint64_t a, uint32_t len) {
+                                   hits.push_back(HgHit{line_no, db->patterns[pi].id, to});
+                                   aux.push_back(HgHitAux{a, len, pi});
+                                 });
+        if (data[s] == '\n') rank++;
+      }
+    }
+  }
+  uint64_t raw = hits.size();
+  // ---- order + dedupe
+  std::vector<uint32_t> order(hits.size());
+  for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+    uint64_t kx = hg_sort_key(hits[x], db->patterns[aux[x].pattern].single), ky = hg_sort_key(hits[y], db->patterns[aux[y].pattern].single);
+    if (hits[x].line_no != hits[y].line_no) return hits[x].line_no < hits[y].line_no;
+    return kx < ky;
+  });
+  std::vector<HgHit> sh(hits.size());
+  std::vector<HgHitAux> sa(hits.size());
+  for (size_t i = 0; i < order.size(); i++) { sh[i] = hits[order[i]]; sa[i] = aux[order[i]]; }
+  std::vector<SimHit> kept;
+  for (size_t i = 0; i < sh.size(); i++) {
+    if (!hg_keep_hit(sh.data(), sa.data(), v.patterns, i)) continue;
+    kept.push_back(SimHit{sh[i].line_no, sh[i].id, sh[i].to, sa[i].start, sa[i].len, sa[i].pattern});
+  }
+  SimHit *res = static_cast<SimHit *>(malloc(sizeof(SimHit) * (kept.size() ? kept.size() : 1)));
+  std::memcpy(res, kept.data(), sizeof(SimHit) * kept.size());
+  *out = res;
+  if (stats) { stats[0] = bitmap_hits; stats[1] = cands.size(); stats[2] = raw; stats[3] = pieces; }
+  return static_cast<long>(kept.size());
+}
+void hgsim_free_hits(SimHit *p) { free(p); }
+}

@@ -1,0 +1,170 @@
+"""CPU tests of the product's pattern compiler and of the scalar device logic (hg_core.h / hg_post.h),
+replayed on the host by tests/native/hostsim.cpp and compared with the oracle."""
+from __future__ import annotations
+
+import random
+
+import pytest
+
+import hgsim_py
+import oracle_py
+import regex_gen
+from test_oracle import ACCEPTED, REJECTED
+
+
+def oracle_hits(data, patterns, flags=None, ids=None, buffer_size=262140):
+    rc, hits, nlines = oracle_py.scan_buffer(data, patterns, flags=flags, ids=ids, buffer_size=buffer_size)
+    assert rc == 0
+    return sorted(hits), nlines
+
+
+def sim_hits(data, patterns, flags=None, ids=None, buffer_size=262140):
+    db = hgsim_py.Db(patterns, flags, ids)
+    assert db.ok(), db.error
+    hits, stats = db.scan(data, buffer_size)
+    return sorted(hits), stats, db
+
+
+@pytest.mark.parametrize("pat", REJECTED)
+def test_rejects_like_oracle(pat):
+    assert not hgsim_py.Db([pat]).ok()
+
+
+@pytest.mark.parametrize("pat", ACCEPTED)
+def test_accepts_like_oracle(pat):
+    db = hgsim_py.Db([pat])
+    assert db.ok(), db.error
+
+
+def test_flag_and_anchor_rules():
+    assert not hgsim_py.Db(["abc"], flags=[16]).ok()
+    assert not hgsim_py.Db(["a^b"], flags=[10]).ok()
+    assert not hgsim_py.Db(["a$b"], flags=[10]).ok()
+    assert hgsim_py.Db(["^ab$"], flags=[10]).ok()
+    assert hgsim_py.Db(["a^b"]).ok()
+
+
+def test_tiers_and_factors():
+    db = hgsim_py.Db(["foobar", "needle_in_haystack", "user=[a-z0-9_]{4,12} status=5[0-9]{2}", "[a-z]+@[a-z]+",
+                      "(alpha_long_one|beta_long_two)x", "(?i)CaseLessLiteral"])
+    assert db.ok(), db.error
+    assert [db.tier(i) for i in range(6)] == [1, 0, 0, 1, 0, 0]
+    info = db.info()
+    assert info["nslow"] == 2 and info["fold_mask"] == 0x20202020
+    assert info["nfactors"] == 5 and info["nwindows"] == 20
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_patterns_match_oracle(seed):
+    rng = random.Random(5000 + seed)
+    done = 0
+    for _ in range(40):
+        k = rng.randint(1, 3)
+        pats = [regex_gen.random_pattern(rng) for _ in range(k)]
+        flags = [rng.choice([14, 14, 15, 10, 6, 12]) for _ in range(k)]
+        ids = [rng.randint(0, 2) for _ in range(k)]
+        if oracle_py.check_patterns(pats, flags=flags) != 0:
+            continue
+        db = hgsim_py.Db(pats, flags, ids)
+        if not db.ok():
+            continue  # documented frontier differences are checked elsewhere
+        data = regex_gen.random_text(rng, 40, final_newline=rng.random() < 0.8)
+        want, nlines = oracle_hits(data, pats, flags, ids)
+        got, stats = db.scan(data)
+        assert sorted(got) == want, (pats, flags, ids, data)
+        done += 1
+    assert done > 10
+
+
+def _log_text(rng, nlines, needles, p_hit=0.2, maxlen=120):
+    words = ["alpha", "beta", "gamma", "delta", "status=200", "user=bob", "GET", "/index.html", "10.0.0.1", "ok",
+             "warn", "retry", "timeout=30", "id=12345", "x"]
+    out = []
+    for _ in range(nlines):
+        n = rng.randint(0, 12)
+        toks = [rng.choice(words) for _ in range(n)]
+        if needles and rng.random() < p_hit:
+            toks.insert(rng.randint(0, len(toks)), rng.choice(needles))
+        out.append(" ".join(toks)[:maxlen])
+    return ("\n".join(out) + "\n").encode()
+
+
+def test_literal_anchored_tier_matches_oracle():
+    rng = random.Random(77)
+    pats = ["needle_in_haystack", "ERR_DISK_FULL_[0-9]{3}", "user=[a-z0-9_]{4,12} status=5[0-9]{2}",
+            "(?i)caseless_needle", "(first_long_alt|second_long_alt) tail", "connection reset by peer$",
+            "^kernel panic -", "\\bwordbound_token\\b"]
+    needles = ["needle_in_haystack", "ERR_DISK_FULL_042", "ERR_DISK_FULL_04", "user=alice_01 status=503",
+               "user=al status=503", "CaseLess_Needle", "first_long_alt tail", "second_long_alt tail",
+               "second_long_alt  tail", "connection reset by peer", "kernel panic - not syncing",
+               "wordbound_token", "xwordbound_tokenx", "needle_in_haystac"]
+    data = _log_text(rng, 3000, needles)
+    for ids in (None, list(range(len(pats)))):
+        want, nlines = oracle_hits(data, pats, ids=ids)
+        got, stats, db = sim_hits(data, pats, ids=ids)
+        assert all(db.tier(i) == 0 for i in range(len(pats)))
+        assert got == want
+        assert stats["pieces"] == nlines
+        assert len(want) > 100
+
+
+def test_tile_boundaries_and_long_lines():
+    rng = random.Random(3)
+    pat = ["needle_in_haystack", "tail_anchor_zz$"]
+    # lines whose literals straddle 16 KiB tile boundaries, lines longer than a tile, and a line longer than bs1
+    chunks = []
+    pos = 0
+    for i in range(40):
+        pad = rng.randint(0, 9000)
+        line = b"a" * pad + b" needle_in_haystack " + b"b" * rng.randint(0, 9000) + b" tail_anchor_zz\n"
+        chunks.append(line)
+        pos += len(line)
+    chunks.append(b"q" * 70000 + b"needle_in_haystack" + b"r" * 70000 + b"tail_anchor_zz\n")
+    chunks.append(b"short needle_in_haystack\n")
+    chunks.append(b"no newline at end needle_in_haystack tail_anchor_zz")
+    data = b"".join(chunks)
+    for bs in (262140, 20001, 16385):
+        want, nlines = oracle_hits(data, pat, ids=[0, 1], buffer_size=bs)
+        got, stats, _ = sim_hits(data, pat, ids=[0, 1], buffer_size=bs)
+        assert got == want, bs
+        assert stats["pieces"] == nlines
+
+
+def test_straddle_every_alignment():
+    lit = "needle_in_haystack"
+    for shift in range(0, 40):
+        data = b"x" * (16384 - 20 + shift) + lit.encode() + b"\nnext line\n"
+        want, _ = oracle_hits(data, [lit])
+        got, _, _ = sim_hits(data, [lit])
+        assert got == want and len(got) == 1
+
+
+def test_nul_rules_match_oracle():
+    pats = ["needle_in_haystack", "x"]
+    data = (b"\0\0needle_in_haystack\n" b"ab\0needle_in_haystack x\n" b"x\0\0\n" b"\0\n" b"needle_in_haystack\0x\n"
+            b"\0\0\0")
+    for ids in (None, [1, 2]):
+        want, nlines = oracle_hits(data, pats, ids=ids)
+        got, stats, _ = sim_hits(data, pats, ids=ids)
+        assert got == want
+        assert stats["pieces"] == nlines
+
+
+def test_not_singlematch_and_mixed_ids():
+    data = b"aaa needle_in_haystack needle_in_haystack\nba\n"
+    pats = ["a", "needle_in_haystack", "needle"]
+    flags = [6, 6, 14]
+    ids = [0, 1, 1]
+    want, _ = oracle_hits(data, pats, flags, ids)
+    got, _, _ = sim_hits(data, pats, flags, ids)
+    assert got == want
+
+
+def test_many_patterns_share_windows():
+    rng = random.Random(11)
+    lits = ["tok_%04x_%s" % (i, "".join(rng.choice("abcdef") for _ in range(rng.randint(2, 10)))) for i in range(300)]
+    data = _log_text(rng, 2000, lits, p_hit=0.3)
+    want, _ = oracle_hits(data, lits, ids=list(range(len(lits))))
+    got, stats, db = sim_hits(data, lits, ids=list(range(len(lits))))
+    assert got == want and len(got) > 300
+    assert db.info()["nslow"] == 0
