@@ -1,0 +1,68 @@
+"""Build recipe for the native library: hipcc (gfx950) for the kernels / engine / C ABI, g++ for the pattern compiler.
+
+The result lands IN-TREE at hypergrep_amd/lib/libhyperscanner.so (the name the reference's loader expects,
+hypergrep/utils.py:79) so that it travels with the source snapshot; objects go to build/.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIB_DIR = os.path.join(PKG, "lib")
+LIB = os.path.join(LIB_DIR, "libhyperscanner.so")
+OBJ = os.path.join(REPO, "build", "obj")
+
+HIP_SOURCES = ["hg_kernels.hip", "hg_engine.hip", "hg_capi.hip", "hg_shim.hip", "hg_hsface.hip"]
+CXX_SOURCES = ["hg_compile.cpp"]
+HEADERS = ["hg_db.h", "hg_core.h", "hg_post.h", "hg_engine.h", "hg_compile.h", "hg_synth.h"]
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the native library can only be built with the ROCm toolchain")
+
+
+def _stale(target: str, deps: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(verbose: bool = False, force: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    common_deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(REPO, "include", "hypergrep_amd.h")]
+    objs = []
+    for src in HIP_SOURCES + CXX_SOURCES:
+        path = os.path.join(CSRC, src)
+        if not os.path.exists(path):
+            continue
+        obj = os.path.join(OBJ, src + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [path] + common_deps):
+            if src.endswith(".hip"):
+                cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-c", path, "-o", obj]
+            else:
+                cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-c", path, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs + ["-lz", "-ldl", "-Wl,-Bsymbolic", "-Wl,-soname,libhyperscanner.so"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(verbose=True, force="--force" in sys.argv))

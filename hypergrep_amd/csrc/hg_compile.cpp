@@ -858,7 +858,7 @@ Lit clip(const Lit &l) {
 
 }  // namespace
 
-int hg_compile(const char *const *exprs, const unsigned *flags, const unsigned *ids, unsigned n, HgDb **out,
+int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned *ids, unsigned n, HgDb **out,
                std::string *err, int *bad_index) {
   if (bad_index) *bad_index = -1;
   if (out) *out = nullptr;
@@ -1017,4 +1017,4 @@ int hg_compile(const char *const *exprs, const unsigned *flags, const unsigned *
   return 0;
 }
 
-void hg_db_free(HgDb *db) { delete db; }
+void hgc_free(HgDb *db) { delete db; }

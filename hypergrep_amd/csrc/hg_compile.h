@@ -21,6 +21,6 @@ struct HgDb {
 };
 
 // Returns 0 on success.  On failure returns non-zero, sets *err and *bad_index (expression index or -1).
-int hg_compile(const char *const *exprs, const unsigned *flags, const unsigned *ids, unsigned n, HgDb **out,
+int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned *ids, unsigned n, HgDb **out,
                std::string *err, int *bad_index);
-void hg_db_free(HgDb *db);
+void hgc_free(HgDb *db);

@@ -17,7 +17,7 @@ struct HgTileSum {
   uint32_t nl_count;  // '\n' bytes in the tile
   uint32_t first_nl;  // tile-relative offset of the first / last '\n' (HG_NONE32 if none)
   uint32_t last_nl;
-  uint32_t pad;
+  uint32_t inner;     // pieces of the lines between the first and the last '\n' (nl_count - 1 unless lines are split)
 };
 // Prefix state at the start of a tile, written by the tile-scan kernel.
 struct HgTileBase {
@@ -102,13 +102,28 @@ HG_HD void hg_verify_window(const HgDbView &db, const uint8_t *text, uint64_t nb
 // Pieces of the carry-in line of a tile: ceil(len / bs1), len >= 1.
 HG_HD uint64_t hg_pieces(uint64_t len, uint64_t bs1) { return (len + bs1 - 1) / bs1; }
 
-// Piece index of the line that starts at a position with `rank` newlines before it in tile `t`
-// (rank == 0: the carry-in line itself).  Requires bs1 >= HG_TILE_BYTES so that lines lying inside one
-// tile are single pieces.
-HG_HD uint64_t hg_line_index(const HgTileSum &ts, const HgTileBase &tb, uint64_t tile_start, uint32_t rank, uint64_t bs1) {
+// Pieces of the whole lines lying in [from, to): both are line starts (to is just past a '\n').
+HG_HD uint64_t hg_inner_pieces(const uint8_t *text, uint64_t from, uint64_t to, uint64_t bs1) {
+  uint64_t total = 0, start = from;
+  for (uint64_t i = from; i < to; i++)
+    if (text[i] == '\n') {
+      total += hg_pieces(i + 1 - start, bs1);
+      start = i + 1;
+    }
+  return total;
+}
+
+// Piece index of the line that starts at absolute offset `s`, which has `rank` newlines before it in
+// tile `t` (rank == 0: the carry-in line itself).  When bs1 >= HG_TILE_BYTES every line lying inside one
+// tile is a single piece and the answer is arithmetic; otherwise (`small`) the lines between the tile's
+// first newline and `s` are walked.
+HG_HD uint64_t hg_line_index(const uint8_t *text, const HgTileSum &ts, const HgTileBase &tb, uint64_t tile_start, uint32_t rank,
+                             uint64_t s, uint64_t bs1, bool small) {
   if (rank == 0) return tb.L;
-  uint64_t carry_len = tile_start + ts.first_nl + 1 - tb.cs;
-  return tb.L + hg_pieces(carry_len, bs1) + (rank - 1);
+  uint64_t after_first = tile_start + ts.first_nl + 1;
+  uint64_t base = tb.L + hg_pieces(after_first - tb.cs, bs1);
+  if (!small) return base + (rank - 1);
+  return base + hg_inner_pieces(text, after_first, s, bs1);
 }
 
 // Bytes hs_scan would see for the piece [ps, limit): skip leading NULs, cut at the first NUL or after the
@@ -195,7 +210,7 @@ HG_HD void hg_confirm(const HgDbView &db, const uint8_t *text, uint64_t nbytes, 
   }
   uint64_t k = (pos - s) / bs1;
   uint64_t ps = s + k * bs1;
-  uint64_t line_no = hg_line_index(sums[t], bases[t], tile_start, rank, bs1) + k;
+  uint64_t line_no = hg_line_index(text, sums[t], bases[t], tile_start, rank, s, bs1, bs1 < HG_TILE_BYTES) + k;
   uint64_t limit = ps + bs1 < nbytes ? ps + bs1 : nbytes;
   uint64_t a, z;
   hg_trim_piece(text, ps, limit, a, z);
@@ -210,7 +225,7 @@ template <typename Emit>
 HG_HD void hg_scan_line_always_on(const HgDbView &db, const uint8_t *text, uint64_t nbytes, const HgTileSum *sums,
                                   const HgTileBase *bases, uint64_t bs1, uint64_t s, uint32_t rank, Emit &&emit) {
   uint64_t t = s >> HG_TILE_SHIFT, tile_start = t << HG_TILE_SHIFT;
-  uint64_t line_no = hg_line_index(sums[t], bases[t], tile_start, rank, bs1);
+  uint64_t line_no = hg_line_index(text, sums[t], bases[t], tile_start, rank, s, bs1, bs1 < HG_TILE_BYTES);
   uint64_t ps = s;
   for (;;) {
     uint64_t limit = ps + bs1 < nbytes ? ps + bs1 : nbytes;

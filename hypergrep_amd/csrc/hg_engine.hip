@@ -1,0 +1,332 @@
+// Host side of the device scanner: uploads the compiled database, owns the workspace in HBM and issues
+// the launch sequence (stream pass -> tile scan -> confirm / always-on -> order + de-duplicate).
+// There is no CPU scan path here: any HIP failure is reported as HG_ERR_HIP.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+
+#include "hg_engine.h"
+
+#include <rocprim/rocprim.hpp>
+
+// kernels (hg_kernels.hip)
+__global__ void hg_stream_kernel(HgStreamArgs a);
+__global__ void hg_tile_reduce_kernel(const HgTileSum *sums, uint64_t ntiles, uint64_t bs1, HgTileElem *agg);
+__global__ void hg_tile_spine_kernel(const HgTileElem *agg, uint32_t nblocks, uint64_t bs1, HgTileBase init, HgTileBase *block_base,
+                                     HgTileBase *final_state);
+__global__ void hg_tile_apply_kernel(const HgTileSum *sums, uint64_t ntiles, uint64_t bs1, const HgTileBase *block_base, HgTileBase *bases);
+__global__ void hg_tile_inner_kernel(const uint8_t *text, HgTileSum *sums, uint64_t ntiles, uint64_t bs1);
+__global__ void hg_confirm_kernel(HgConfirmArgs a);
+__global__ void hg_always_on_kernel(HgConfirmArgs a);
+__global__ void hg_key_kernel(const HgHit *hits, const HgHitAux *aux, const HgPattern *patterns, uint32_t n, uint64_t *key, uint32_t *idx);
+__global__ void hg_line_key_kernel(const HgHit *hits, const uint32_t *perm, uint32_t n, uint64_t *key);
+__global__ void hg_gather_kernel(const HgHit *hits, const HgHitAux *aux, const uint32_t *perm, uint32_t n, HgHit *oh, HgHitAux *oa);
+__global__ void hg_keep_kernel(const HgHit *hits, const HgHitAux *aux, const HgPattern *patterns, uint32_t n, uint8_t *keep);
+
+namespace {
+constexpr int TS_BLOCK_TILES = 1024;  // must match hg_kernels.hip (256 threads x 4 tiles)
+constexpr int STREAM_WG_WAVES = 8;
+
+template <typename T>
+hipError_t upload(void **dst, const std::vector<T> &src) {
+  size_t bytes = std::max<size_t>(src.size() * sizeof(T), 16);
+  hipError_t e = hipMalloc(dst, bytes);
+  if (e != hipSuccess) return e;
+  if (!src.empty()) e = hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
+  return e;
+}
+uint32_t bits_for(uint64_t v) {
+  uint32_t b = 1;
+  while (b < 64 && (v >> b)) b++;
+  return b;
+}
+}  // namespace
+
+bool HgScanner::fail(hipError_t e, const char *what) {
+  if (e == hipSuccess) return false;
+  err_ = std::string(what) + ": " + hipGetErrorString(e);
+  return true;
+}
+
+int HgScanner::create(const HgDb *db, int device, HgScanner **out, std::string *err) {
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0) {
+    if (err) *err = std::string("no HIP device available (") + hipGetErrorString(e) + "); the scan path has no CPU fallback";
+    return HG_ERR_HIP;
+  }
+  if (device < 0 || device >= count) {
+    if (err) *err = "device index out of range";
+    return HG_ERR_ARG;
+  }
+  std::unique_ptr<HgScanner> s(new HgScanner());
+  s->device_ = device;
+  s->db_ = db;
+#define HG_TRY(call, what)                         \
+  if (s->fail((call), what)) {                     \
+    if (err) *err = s->err_;                       \
+    return HG_ERR_HIP;                             \
+  }
+  HG_TRY(hipSetDevice(device), "hipSetDevice");
+  hipDeviceProp_t prop;
+  HG_TRY(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
+  s->num_cus_ = prop.multiProcessorCount;
+  HG_TRY(upload(&s->d_patterns_, db->patterns), "upload patterns");
+  HG_TRY(upload(&s->d_pool_, db->pool), "upload tables");
+  HG_TRY(upload(&s->d_factors_, db->factors), "upload factors");
+  HG_TRY(upload(&s->d_windows_, db->windows), "upload windows");
+  HG_TRY(upload(&s->d_bucket_, db->bucket_off), "upload buckets");
+  HG_TRY(upload(&s->d_bitmap_, db->bitmap), "upload bitmap");
+  HG_TRY(upload(&s->d_slow_, db->slow), "upload always-on list");
+  s->view_.patterns = static_cast<const HgPattern *>(s->d_patterns_);
+  s->view_.pool = static_cast<const uint32_t *>(s->d_pool_);
+  s->view_.factors = static_cast<const HgFactor *>(s->d_factors_);
+  s->view_.windows = static_cast<const HgWindow *>(s->d_windows_);
+  s->view_.bucket_off = static_cast<const uint32_t *>(s->d_bucket_);
+  s->view_.slow = static_cast<const uint32_t *>(s->d_slow_);
+  s->view_.npatterns = static_cast<uint32_t>(db->patterns.size());
+  s->view_.nslow = static_cast<uint32_t>(db->slow.size());
+  s->view_.fold_mask = db->fold_mask;
+  HG_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_counters_), HG_CNT_WORDS * 4), "alloc counters");
+  HG_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_selected_), 16), "alloc counters");
+  HG_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_final_), sizeof(HgTileBase)), "alloc state");
+  HG_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_counters_), (HG_CNT_WORDS + 4) * 4), "alloc pinned");
+  HG_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_final_), sizeof(HgTileBase)), "alloc pinned");
+  for (auto &ev : s->ev_) HG_TRY(hipEventCreate(&ev), "hipEventCreate");
+#undef HG_TRY
+  *out = s.release();
+  return HG_OK;
+}
+
+HgScanner::~HgScanner() {
+  (void)hipSetDevice(device_);
+  void *ptrs[] = {d_patterns_, d_pool_, d_factors_, d_windows_, d_bucket_, d_bitmap_, d_slow_, d_sums_, d_bases_, d_block_base_,
+                  d_final_, d_agg_, d_cands_, d_hits_raw_, d_hits_sorted_, d_hits_out_, d_aux_raw_, d_aux_sorted_, d_aux_out_,
+                  d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, d_keep_, d_counters_, d_selected_, d_temp_};
+  for (void *p : ptrs)
+    if (p) (void)hipFree(p);
+  if (h_counters_) (void)hipHostFree(h_counters_);
+  if (h_final_) (void)hipHostFree(h_final_);
+  for (auto &ev : ev_)
+    if (ev) (void)hipEventDestroy(ev);
+}
+
+int HgScanner::ensure(uint64_t nbytes) {
+  uint64_t ntiles = std::max<uint64_t>((nbytes + HG_TILE_BYTES - 1) / HG_TILE_BYTES, 1);
+  auto re = [&](auto *&ptr, size_t count) -> bool {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    return fail(hipMalloc(reinterpret_cast<void **>(&ptr), std::max<size_t>(count * sizeof(*ptr), 16)), "workspace alloc");
+  };
+  if (ntiles > cap_tiles_) {
+    uint64_t nblocks = (ntiles + TS_BLOCK_TILES - 1) / TS_BLOCK_TILES;
+    if (re(d_sums_, ntiles) || re(d_bases_, ntiles + 1) || re(d_agg_, nblocks) || re(d_block_base_, nblocks)) return HG_ERR_HIP;
+    cap_tiles_ = ntiles;
+  }
+  // one candidate / hit per KiB of text to start with; grows on overflow
+  uint64_t want = std::max<uint64_t>(nbytes / 1024, 1u << 16);
+  want = std::min<uint64_t>(want, 0x7FFFFFF0u);
+  if (cand_cap_ < want) {
+    if (re(d_cands_, want)) return HG_ERR_HIP;
+    cand_cap_ = static_cast<uint32_t>(want);
+  }
+  if (hit_cap_ < want) {
+    uint32_t n = static_cast<uint32_t>(want);
+    if (re(d_hits_raw_, n) || re(d_hits_sorted_, n) || re(d_hits_out_, n) || re(d_aux_raw_, n) || re(d_aux_sorted_, n) ||
+        re(d_aux_out_, n) || re(d_key_a_, n) || re(d_key_b_, n) || re(d_perm_a_, n) || re(d_perm_b_, n) || re(d_keep_, n))
+      return HG_ERR_HIP;
+    hit_cap_ = n;
+    size_t t1 = 0, t2 = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, t1, d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, n, 0, 64, hipStream_t(nullptr));
+    (void)rocprim::select(nullptr, t2, d_hits_sorted_, d_keep_, d_hits_out_, d_selected_, n, hipStream_t(nullptr));
+    size_t need = std::max(t1, t2) + 256;
+    if (need > temp_bytes_) {
+      if (d_temp_) (void)hipFree(d_temp_);
+      d_temp_ = nullptr;
+      if (fail(hipMalloc(&d_temp_, need), "workspace alloc")) return HG_ERR_HIP;
+      temp_bytes_ = need;
+    }
+  }
+  return HG_OK;
+}
+
+int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint64_t line_base, hipStream_t stream, HgScanOutput *out,
+                        bool *overflow) {
+  *overflow = false;
+  const uint64_t ntiles = (nbytes + HG_TILE_BYTES - 1) / HG_TILE_BYTES;
+  const uint32_t nblocks = static_cast<uint32_t>((ntiles + TS_BLOCK_TILES - 1) / TS_BLOCK_TILES);
+#define HG_TRY(call, what) \
+  if (fail((call), what)) return HG_ERR_HIP;
+  HG_TRY(hipMemsetAsync(d_counters_, 0, HG_CNT_WORDS * 4, stream), "memset counters");
+  HG_TRY(hipEventRecord(ev_[0], stream), "event");
+
+  HgStreamArgs sa{};
+  sa.text = text;
+  sa.nbytes = nbytes;
+  sa.ntiles = ntiles;
+  sa.db = view_;
+  sa.bitmap = static_cast<const uint32_t *>(d_bitmap_);
+  sa.sums = d_sums_;
+  sa.cands = d_cands_;
+  sa.cand_cap = cand_cap_;
+  sa.counters = d_counters_;
+  if (ntiles) {
+    uint32_t wgs = static_cast<uint32_t>(std::min<uint64_t>((ntiles + STREAM_WG_WAVES - 1) / STREAM_WG_WAVES, static_cast<uint64_t>(num_cus_) * 2));
+    HG_TRY(hipEventRecord(ev_[1], stream), "event");
+    hipLaunchKernelGGL(hg_stream_kernel, dim3(wgs), dim3(STREAM_WG_WAVES * 64), 0, stream, sa);
+    HG_TRY(hipGetLastError(), "hg_stream_kernel launch");
+    HG_TRY(hipEventRecord(ev_[2], stream), "event");
+
+    if (bs1 < HG_TILE_BYTES) {  // small-buffer mode: lines inside a tile can split, re-price the tile summaries
+      uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((ntiles + 255) / 256, 4096));
+      hipLaunchKernelGGL(hg_tile_inner_kernel, dim3(blocks), dim3(256), 0, stream, text, d_sums_, ntiles, bs1);
+    }
+    HgTileBase init{0, line_base};
+    hipLaunchKernelGGL(hg_tile_reduce_kernel, dim3(nblocks), dim3(256), 0, stream, d_sums_, ntiles, bs1, d_agg_);
+    hipLaunchKernelGGL(hg_tile_spine_kernel, dim3(1), dim3(256), 0, stream, d_agg_, nblocks, bs1, init, d_block_base_, d_final_);
+    hipLaunchKernelGGL(hg_tile_apply_kernel, dim3(nblocks), dim3(256), 0, stream, d_sums_, ntiles, bs1, d_block_base_, d_bases_);
+    HG_TRY(hipGetLastError(), "tile scan launch");
+
+    HgConfirmArgs ca{};
+    ca.text = text;
+    ca.nbytes = nbytes;
+    ca.ntiles = ntiles;
+    ca.bs1 = bs1;
+    ca.db = view_;
+    ca.sums = d_sums_;
+    ca.bases = d_bases_;
+    ca.cands = d_cands_;
+    ca.hits = d_hits_raw_;
+    ca.aux = d_aux_raw_;
+    ca.cand_cap = cand_cap_;
+    ca.hit_cap = hit_cap_;
+    ca.counters = d_counters_;
+    if (db_->patterns.size() > db_->slow.size()) {
+      hipLaunchKernelGGL(hg_confirm_kernel, dim3(static_cast<uint32_t>(num_cus_) * 8), dim3(256), 0, stream, ca);
+      HG_TRY(hipGetLastError(), "hg_confirm_kernel launch");
+    }
+    if (!db_->slow.empty()) {
+      uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((ntiles + 3) / 4, static_cast<uint64_t>(num_cus_) * 8));
+      hipLaunchKernelGGL(hg_always_on_kernel, dim3(blocks), dim3(256), 0, stream, ca);
+      HG_TRY(hipGetLastError(), "hg_always_on_kernel launch");
+    }
+    HG_TRY(hipMemcpyAsync(h_final_, d_final_, sizeof(HgTileBase), hipMemcpyDeviceToHost, stream), "copy state");
+  } else {
+    HG_TRY(hipEventRecord(ev_[1], stream), "event");
+    HG_TRY(hipEventRecord(ev_[2], stream), "event");
+    h_final_->cs = 0;
+    h_final_->L = line_base;
+  }
+  HG_TRY(hipMemcpyAsync(h_counters_, d_counters_, HG_CNT_WORDS * 4, hipMemcpyDeviceToHost, stream), "copy counters");
+  HG_TRY(hipStreamSynchronize(stream), "stream sync (scan kernels)");
+
+  const uint64_t n_cands = h_counters_[HG_CNT_CANDS], n_raw = h_counters_[HG_CNT_HITS];
+  if (n_cands > cand_cap_ || n_raw > hit_cap_) {
+    // grow and let the caller repeat the pass: nothing is dropped silently
+    uint64_t want_c = std::min<uint64_t>(std::max<uint64_t>(n_cands + n_cands / 4, cand_cap_), 0x7FFFFFF0u);
+    uint64_t want_h = std::min<uint64_t>(std::max<uint64_t>(std::max(n_raw, n_cands) * 5 / 4, hit_cap_), 0x7FFFFFF0u);
+    if ((n_cands > cand_cap_ && want_c <= cand_cap_) || (n_raw > hit_cap_ && want_h <= hit_cap_)) {
+      err_ = "more than 2^31 candidates in one scan call: split the buffer";
+      return HG_ERR_ARG;
+    }
+    auto grow = [&](auto *&ptr, size_t count) {
+      if (ptr) (void)hipFree(ptr);
+      ptr = nullptr;
+      return fail(hipMalloc(reinterpret_cast<void **>(&ptr), count * sizeof(*ptr)), "workspace grow");
+    };
+    if (want_c > cand_cap_) {
+      if (grow(d_cands_, want_c)) return HG_ERR_HIP;
+      cand_cap_ = static_cast<uint32_t>(want_c);
+    }
+    if (want_h > hit_cap_) {
+      uint32_t n = static_cast<uint32_t>(want_h);
+      if (grow(d_hits_raw_, n) || grow(d_hits_sorted_, n) || grow(d_hits_out_, n) || grow(d_aux_raw_, n) || grow(d_aux_sorted_, n) ||
+          grow(d_aux_out_, n) || grow(d_key_a_, n) || grow(d_key_b_, n) || grow(d_perm_a_, n) || grow(d_perm_b_, n) || grow(d_keep_, n))
+        return HG_ERR_HIP;
+      hit_cap_ = n;
+      size_t t1 = 0, t2 = 0;
+      (void)rocprim::radix_sort_pairs(nullptr, t1, d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, n, 0, 64, hipStream_t(nullptr));
+      (void)rocprim::select(nullptr, t2, d_hits_sorted_, d_keep_, d_hits_out_, d_selected_, n, hipStream_t(nullptr));
+      size_t need = std::max(t1, t2) + 256;
+      if (need > temp_bytes_) {
+        if (d_temp_) (void)hipFree(d_temp_);
+        d_temp_ = nullptr;
+        if (fail(hipMalloc(&d_temp_, need), "workspace grow")) return HG_ERR_HIP;
+        temp_bytes_ = need;
+      }
+    }
+    *overflow = true;
+    return HG_OK;
+  }
+
+  uint64_t n_pieces = h_final_->L - line_base + (nbytes > h_final_->cs ? hg_pieces(nbytes - h_final_->cs, bs1) : 0);
+  uint32_t n = static_cast<uint32_t>(n_raw);
+  uint32_t kept = 0;
+  if (n) {
+    const HgPattern *pats = static_cast<const HgPattern *>(d_patterns_);
+    uint32_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(hg_key_kernel, dim3(blocks), dim3(256), 0, stream, d_hits_raw_, d_aux_raw_, pats, n, d_key_a_, d_perm_a_);
+    size_t tb = temp_bytes_;
+    HG_TRY(rocprim::radix_sort_pairs(d_temp_, tb, d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, n, 0, 64, stream), "radix sort (id, to)");
+    hipLaunchKernelGGL(hg_line_key_kernel, dim3(blocks), dim3(256), 0, stream, d_hits_raw_, d_perm_b_, n, d_key_a_);
+    tb = temp_bytes_;
+    uint32_t end_bit = std::min<uint32_t>(64, bits_for(line_base + n_pieces + 1));
+    HG_TRY(rocprim::radix_sort_pairs(d_temp_, tb, d_key_a_, d_key_b_, d_perm_b_, d_perm_a_, n, 0, end_bit, stream), "radix sort (line)");
+    hipLaunchKernelGGL(hg_gather_kernel, dim3(blocks), dim3(256), 0, stream, d_hits_raw_, d_aux_raw_, d_perm_a_, n, d_hits_sorted_, d_aux_sorted_);
+    hipLaunchKernelGGL(hg_keep_kernel, dim3(blocks), dim3(256), 0, stream, d_hits_sorted_, d_aux_sorted_, pats, n, d_keep_);
+    tb = temp_bytes_;
+    HG_TRY(rocprim::select(d_temp_, tb, d_hits_sorted_, d_keep_, d_hits_out_, d_selected_, n, stream), "select hits");
+    tb = temp_bytes_;
+    HG_TRY(rocprim::select(d_temp_, tb, d_aux_sorted_, d_keep_, d_aux_out_, d_selected_, n, stream), "select aux");
+    HG_TRY(hipGetLastError(), "finalize launch");
+    HG_TRY(hipMemcpyAsync(h_counters_ + HG_CNT_WORDS, d_selected_, 4, hipMemcpyDeviceToHost, stream), "copy count");
+  }
+  HG_TRY(hipEventRecord(ev_[3], stream), "event");
+  HG_TRY(hipStreamSynchronize(stream), "stream sync (finalize)");
+  if (n) kept = h_counters_[HG_CNT_WORDS];
+  out->n_hits = kept;
+  out->n_pieces = n_pieces;
+  out->n_cands = n_cands;
+  out->n_raw_hits = n_raw;
+  out->d_hits = d_hits_out_;
+  out->d_aux = d_aux_out_;
+  out->ms_stream = 0;
+  out->ms_total = 0;
+  (void)hipEventElapsedTime(&out->ms_stream, ev_[1], ev_[2]);
+  (void)hipEventElapsedTime(&out->ms_total, ev_[0], ev_[3]);
+#undef HG_TRY
+  return HG_OK;
+}
+
+int HgScanner::scan(const void *d_text, uint64_t nbytes, int buffer_size, uint64_t line_base, hipStream_t stream, HgScanOutput *out) {
+  if (!out || (!d_text && nbytes) || buffer_size < 2) {
+    err_ = "invalid arguments";
+    return HG_ERR_ARG;
+  }
+  if ((reinterpret_cast<uintptr_t>(d_text) & 15u) != 0) {
+    err_ = "text pointer must be 16-byte aligned";
+    return HG_ERR_ARG;
+  }
+  const uint64_t bs1 = static_cast<uint64_t>(buffer_size) - 1;
+  if (fail(hipSetDevice(device_), "hipSetDevice")) return HG_ERR_HIP;
+  std::memset(out, 0, sizeof(*out));
+  int rc = ensure(nbytes);
+  if (rc) return rc;
+  uint32_t reruns = 0;
+  for (;;) {
+    bool overflow = false;
+    rc = run_once(static_cast<const uint8_t *>(d_text), nbytes, bs1, line_base, stream, out, &overflow);
+    if (rc) return rc;
+    if (!overflow) break;
+    if (++reruns > 8) {
+      err_ = "workspace kept overflowing";
+      return HG_ERR_NOMEM;
+    }
+    if (std::getenv("HG_VERBOSE")) std::fprintf(stderr, "hypergrep_amd: workspace grown (cands %u, hits %u), repeating the pass\n", cand_cap_, hit_cap_);
+  }
+  out->reruns = reruns;
+  return HG_OK;
+}

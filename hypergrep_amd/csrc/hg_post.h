@@ -16,12 +16,12 @@ HG_HD HgTileElem hg_tile_elem(const HgTileSum &s, uint64_t tile_start) {
   e.has_nl = s.nl_count != 0;
   e.pad = 0;
   e.k1 = e.has_nl ? tile_start + s.first_nl + 1 : 0;
-  e.d = e.has_nl ? s.nl_count - 1 : 0;
+  e.d = e.has_nl ? s.inner : 0;
   e.new_cs = e.has_nl ? tile_start + s.last_nl + 1 : 0;
   return e;
 }
-// a then b.  Lines that start and end inside the run are single pieces (bs1 >= tile size), except the one
-// that crosses from a's last newline to b's first newline, which is priced here.
+// a then b.  Lines inside each run are already priced in d; the line that crosses from a's last newline to
+// b's first newline is priced here.
 HG_HD HgTileElem hg_tile_combine(const HgTileElem &a, const HgTileElem &b, uint64_t bs1) {
   if (!a.has_nl) return b;
   if (!b.has_nl) return a;

@@ -1,0 +1,418 @@
+// Face B: hyperscan() and check_patterns() with the reference shim's exact C ABI
+// (hypergrep/lib/c/hyperscanner.c:154-159, :248-258), so hypergrep/utils.py:116-121 and :339-349 can call
+// this library unchanged.  The file is streamed through pinned memory into HBM in large chunks, each
+// chunk is scanned by the device pipeline (HgScanner), and hit records come back to fill the same
+// batched result ring the reference fills in hs_callback() (hyperscanner.c:83-102).
+//
+// What stays on the host: file IO, gzip/zstd decoding (the reference does that on the CPU too, through
+// zlibWrapper), cutting chunks at line boundaries, copying matched line bytes into the result ring and
+// calling back.  No byte of the text is matched on the CPU.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/hypergrep_amd.h"
+#include "hg_compile.h"
+#include "hg_engine.h"
+
+namespace {
+
+// ---------------------------------------------------------------- compiled-database cache
+// The reference recompiles the database for every file (hyperscanner.c:296); here identical pattern sets
+// share one compiled database (and its uploaded copy) for the life of the process.
+std::mutex g_mu;
+std::map<std::string, std::shared_ptr<HgDb>> g_dbs;
+
+std::string db_key(const char *const *patterns, const unsigned *flags, const unsigned *ids, unsigned n) {
+  std::string k;
+  for (unsigned i = 0; i < n; i++) {
+    const char *p = patterns[i] ? patterns[i] : "";
+    uint32_t len = static_cast<uint32_t>(std::strlen(p)), f = flags ? flags[i] : 0, id = ids ? ids[i] : 0;
+    k.append(reinterpret_cast<const char *>(&len), 4);
+    k.append(reinterpret_cast<const char *>(&f), 4);
+    k.append(reinterpret_cast<const char *>(&id), 4);
+    k.append(p, len);
+  }
+  return k;
+}
+
+std::shared_ptr<HgDb> get_db(const char *const *patterns, const unsigned *flags, const unsigned *ids, unsigned n, std::string *err) {
+  if (!patterns || n == 0) {
+    if (err) *err = "no patterns";
+    return nullptr;
+  }
+  for (unsigned i = 0; i < n; i++)
+    if (!patterns[i]) return nullptr;
+  std::string key = db_key(patterns, flags, ids, n);
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_dbs.find(key);
+    if (it != g_dbs.end()) return it->second;
+  }
+  HgDb *raw = nullptr;
+  int bad = -1;
+  if (hgc_compile(patterns, flags, ids, n, &raw, err, &bad) != 0) return nullptr;
+  std::shared_ptr<HgDb> db(raw, [](HgDb *d) { hgc_free(d); });
+  std::lock_guard<std::mutex> lock(g_mu);
+  if (g_dbs.size() >= 16) g_dbs.clear();  // scanners keep their own reference
+  g_dbs[key] = db;
+  return db;
+}
+
+// ---------------------------------------------------------------- per-call device context, pooled
+struct Ctx {
+  std::shared_ptr<HgDb> db;
+  HgScanner *sc = nullptr;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  uint8_t *h_buf = nullptr;  // pinned staging buffer
+  size_t h_cap = 0;
+  uint8_t *d_text = nullptr;
+  size_t d_cap = 0;
+  std::vector<HgHit> hits;
+  std::vector<HgHitAux> aux;
+  ~Ctx() {
+    if (sc) (void)hipSetDevice(device);
+    delete sc;
+    if (h_buf) (void)hipHostFree(h_buf);
+    if (d_text) (void)hipFree(d_text);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+std::vector<Ctx *> g_idle;  // guarded by g_mu; intentionally never destroyed at exit (no HIP calls in static dtors)
+std::atomic<unsigned> g_next_device{0};
+
+Ctx *checkout(const std::shared_ptr<HgDb> &db, std::string *err) {
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    for (size_t i = 0; i < g_idle.size(); i++)
+      if (g_idle[i]->db == db) {
+        Ctx *c = g_idle[i];
+        g_idle.erase(g_idle.begin() + i);
+        return c;
+      }
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    *err = "no HIP device available; hypergrep_amd has no CPU scan path";
+    return nullptr;
+  }
+  int device;
+  if (const char *env = std::getenv("HYPERGREP_DEVICE")) device = std::atoi(env) % ndev;
+  else device = static_cast<int>(g_next_device.fetch_add(1) % static_cast<unsigned>(ndev));  // files shard over the node's GPUs
+  auto c = std::make_unique<Ctx>();
+  c->db = db;
+  c->device = device;
+  if (HgScanner::create(db.get(), device, &c->sc, err) != HG_OK) return nullptr;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    *err = "hipStreamCreate failed";
+    return nullptr;
+  }
+  return c.release();
+}
+void checkin(Ctx *c) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  if (g_idle.size() >= 32) {
+    delete c;
+    return;
+  }
+  g_idle.push_back(c);
+}
+bool ensure_buffers(Ctx *c, size_t cap) {
+  if (c->h_cap < cap) {
+    if (c->h_buf) (void)hipHostFree(c->h_buf);
+    c->h_buf = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void **>(&c->h_buf), cap) != hipSuccess) return false;
+    c->h_cap = cap;
+  }
+  if (c->d_cap < cap) {
+    if (c->d_text) (void)hipFree(c->d_text);
+    c->d_text = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&c->d_text), cap + 16) != hipSuccess) return false;
+    c->d_cap = cap;
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------- input: plain / gzip / zstd
+// gzopen("rb") in the reference (through zstd's zlibWrapper, hyperscanner.c:22,191) auto-detects gzip and
+// zstd by magic and reads anything else verbatim; this reader does the same.
+struct ZIn { const void *src; size_t size, pos; };
+struct ZOut { void *dst; size_t size, pos; };
+struct Zstd {
+  void *lib = nullptr;
+  void *(*create)() = nullptr;
+  size_t (*destroy)(void *) = nullptr;
+  size_t (*step)(void *, ZOut *, ZIn *) = nullptr;
+  unsigned (*is_error)(size_t) = nullptr;
+  bool load() {
+    if (lib) return true;
+    for (const char *name : {"libzstd.so.1", "libzstd.so"}) {
+      lib = dlopen(name, RTLD_NOW);
+      if (lib) break;
+    }
+    if (!lib) return false;
+    create = reinterpret_cast<void *(*)()>(dlsym(lib, "ZSTD_createDStream"));
+    destroy = reinterpret_cast<size_t (*)(void *)>(dlsym(lib, "ZSTD_freeDStream"));
+    step = reinterpret_cast<size_t (*)(void *, ZOut *, ZIn *)>(dlsym(lib, "ZSTD_decompressStream"));
+    is_error = reinterpret_cast<unsigned (*)(size_t)>(dlsym(lib, "ZSTD_isError"));
+    return create && destroy && step && is_error;
+  }
+};
+Zstd g_zstd;
+
+class Reader {
+ public:
+  ~Reader() { close(); }
+  bool open(const char *path) {
+    fd_ = ::open(path, O_RDONLY);
+    if (fd_ < 0) return false;
+    struct stat st;
+    if (fstat(fd_, &st) != 0 || S_ISDIR(st.st_mode)) return false;
+    size_hint_ = S_ISREG(st.st_mode) ? static_cast<size_t>(st.st_size) : 0;
+    unsigned char magic[4] = {0, 0, 0, 0};
+    ssize_t got = ::pread(fd_, magic, 4, 0);
+    if (got >= 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+      gz_ = gzdopen(fd_, "rb");
+      if (!gz_) return false;
+      fd_ = -1;  // owned by zlib now
+      gzbuffer(gz_, 1 << 20);
+      kind_ = 1;
+    } else if (got == 4 && magic[0] == 0x28 && magic[1] == 0xB5 && magic[2] == 0x2F && magic[3] == 0xFD) {
+      std::lock_guard<std::mutex> lock(g_mu);
+      if (!g_zstd.load()) return false;
+      zds_ = g_zstd.create();
+      if (!zds_) return false;
+      zin_.resize(1 << 20);
+      kind_ = 2;
+    }
+    return true;
+  }
+  bool compressed() const { return kind_ != 0; }
+  size_t size_hint() const { return size_hint_; }
+  // Fill dst with up to n bytes; returns bytes produced, 0 at EOF, -1 on error.
+  long read(uint8_t *dst, size_t n) {
+    if (kind_ == 0) {
+      size_t total = 0;
+      while (total < n) {
+        ssize_t r = ::read(fd_, dst + total, n - total);
+        if (r < 0) return -1;
+        if (r == 0) break;
+        total += static_cast<size_t>(r);
+      }
+      return static_cast<long>(total);
+    }
+    if (kind_ == 1) {
+      size_t total = 0;
+      while (total < n) {
+        unsigned want = static_cast<unsigned>(std::min<size_t>(n - total, 1u << 30));
+        int r = gzread(gz_, dst + total, want);
+        if (r < 0) return -1;
+        if (r == 0) break;
+        total += static_cast<size_t>(r);
+      }
+      return static_cast<long>(total);
+    }
+    size_t total = 0;
+    while (total < n) {
+      if (zpos_ == zlen_ && !zeof_) {
+        ssize_t r = ::read(fd_, zin_.data(), zin_.size());
+        if (r < 0) return -1;
+        if (r == 0) zeof_ = true;
+        zlen_ = static_cast<size_t>(r > 0 ? r : 0);
+        zpos_ = 0;
+      }
+      if (zpos_ == zlen_ && zeof_) break;
+      ZIn in{zin_.data(), zlen_, zpos_};
+      ZOut out{dst + total, n - total, 0};
+      size_t rc = g_zstd.step(zds_, &out, &in);
+      if (g_zstd.is_error(rc)) return -1;
+      zpos_ = in.pos;
+      total += out.pos;
+    }
+    return static_cast<long>(total);
+  }
+  void close() {
+    if (gz_) gzclose(gz_);
+    gz_ = nullptr;
+    if (fd_ >= 0) ::close(fd_);
+    fd_ = -1;
+    if (zds_) g_zstd.destroy(zds_);
+    zds_ = nullptr;
+  }
+
+ private:
+  int fd_ = -1, kind_ = 0;
+  gzFile gz_ = nullptr;
+  void *zds_ = nullptr;
+  std::vector<uint8_t> zin_;
+  size_t zpos_ = 0, zlen_ = 0, size_hint_ = 0;
+  bool zeof_ = false;
+};
+
+// ---------------------------------------------------------------- result ring (hyperscanner.c:64-72, :83-102)
+struct Ring {
+  std::vector<hyperscanner_result_t> slots;
+  std::vector<char> storage;
+  int fill = 0;
+  hs_event cb = nullptr;
+  unsigned long long delivered = 0;
+  bool init(int count, int buffer_size, hs_event on_event) {
+    cb = on_event;
+    try {
+      slots.resize(static_cast<size_t>(count));
+      storage.resize(static_cast<size_t>(count) * static_cast<size_t>(buffer_size));
+    } catch (const std::bad_alloc &) {
+      return false;
+    }
+    for (int i = 0; i < count; i++) slots[i].line = storage.data() + static_cast<size_t>(i) * static_cast<size_t>(buffer_size);
+    return true;
+  }
+  void push(unsigned id, unsigned long long line_number, const uint8_t *line, uint32_t len) {
+    hyperscanner_result_t &r = slots[static_cast<size_t>(fill++)];
+    r.id = id;
+    r.line_number = line_number;
+    std::memcpy(r.line, line, len);
+    r.line[len] = 0;
+    delivered++;
+    if (fill == static_cast<int>(slots.size())) flush();
+  }
+  void flush() {
+    if (fill) cb(slots.data(), fill);
+    fill = 0;
+  }
+};
+
+size_t chunk_bytes() {
+  if (const char *env = std::getenv("HYPERGREP_CHUNK_MB")) {
+    long mb = std::atol(env);
+    if (mb >= 1 && mb <= 16384) return static_cast<size_t>(mb) << 20;
+  }
+  return static_cast<size_t>(256) << 20;
+}
+
+}  // namespace
+
+extern "C" int check_patterns(const char *const *patterns, const unsigned int *pattern_flags, const unsigned int *pattern_ids,
+                              const unsigned int elements) {
+  std::string err;
+  return get_db(patterns, pattern_flags, pattern_ids, elements, &err) ? 0 : HYPERSCANNER_DB;
+}
+
+extern "C" int hyperscan(char *file_name, const char *const *patterns, const unsigned int *pattern_flags,
+                         const unsigned int *pattern_ids, const unsigned int elements, hs_event on_event, const int buffer_size,
+                         int buffer_count, unsigned long long max_match_count) {
+  if (max_match_count > 0 && max_match_count < static_cast<unsigned long long>(buffer_count)) buffer_count = static_cast<int>(max_match_count);
+  if (buffer_count < 1 || buffer_size < 1 || !on_event) return HYPERSCANNER_STATE_MEM;
+  Ring ring;
+  if (!ring.init(buffer_count, buffer_size, on_event)) return HYPERSCANNER_COMPILE_MEM;
+
+  std::string err;
+  std::shared_ptr<HgDb> db = get_db(patterns, pattern_flags, pattern_ids, elements, &err);
+  if (!db) {
+    std::fprintf(stderr, "ERROR: Unable to create database. Exiting.\n");
+    return HYPERSCANNER_DB;
+  }
+  Ctx *ctx = checkout(db, &err);
+  if (!ctx) {
+    std::fprintf(stderr, "ERROR: Unable to allocate scratch space. Exiting. (%s)\n", err.c_str());
+    return HYPERSCANNER_SCRATCH;
+  }
+  struct Return {
+    Ctx *c;
+    ~Return() { checkin(c); }
+  } ret_guard{ctx};
+
+  Reader in;
+  if (!file_name || !in.open(file_name)) return HYPERSCANNER_GZ_OPEN;
+  if (buffer_size < 2) return 0;  // gzgets(len <= 1) returns NULL at once: nothing is scanned (hyperscanner.c:199)
+
+  const uint64_t bs1 = static_cast<uint64_t>(buffer_size) - 1;
+  size_t cap = chunk_bytes();
+  if (!in.compressed() && in.size_hint() && in.size_hint() < cap) cap = std::max<size_t>(in.size_hint() + 16, 1 << 16);
+  cap = std::max<size_t>(cap, static_cast<size_t>(std::min<uint64_t>(2 * bs1 + 16, static_cast<uint64_t>(1) << 32)));
+  if (hipSetDevice(ctx->device) != hipSuccess || !ensure_buffers(ctx, cap)) {
+    std::fprintf(stderr, "ERROR: Unable to allocate scratch space. Exiting. (device buffers)\n");
+    return HYPERSCANNER_SCRATCH;
+  }
+
+  uint64_t line_base = 0;  // pieces delivered to the scanner so far == reference line_number of the chunk's first piece
+  size_t have = 0;         // bytes carried over from the previous chunk
+  bool eof = false, stop = false;
+  int rc = 0;
+  while (!stop && (!eof || have)) {
+    while (!eof && have < cap) {
+      long got = in.read(ctx->h_buf + have, cap - have);
+      if (got < 0) { eof = true; break; }  // a read error ends the stream like gzgets returning NULL
+      if (got == 0) { eof = true; break; }
+      have += static_cast<size_t>(got);
+    }
+    if (!have) break;
+    // cut the chunk at a piece boundary so that every piece is scanned whole
+    size_t cut = have;
+    if (!eof) {
+      const void *nl = memrchr(ctx->h_buf, '\n', have);
+      if (nl) cut = static_cast<size_t>(static_cast<const uint8_t *>(nl) - ctx->h_buf) + 1;
+      else cut = static_cast<size_t>((have / bs1) * bs1);  // one unterminated line: stop at a forced break
+      if (!cut) cut = have;
+    }
+    if (hipMemcpyAsync(ctx->d_text, ctx->h_buf, cut, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = HYPERSCANNER_SCAN; break; }
+    HgScanOutput out{};
+    int src = ctx->sc->scan(ctx->d_text, cut, buffer_size, line_base, ctx->stream, &out);
+    if (src != HG_OK) {
+      std::fprintf(stderr, "ERROR: Unable to scan buffer. Exiting. (%s)\n", ctx->sc->last_error().c_str());
+      rc = HYPERSCANNER_SCAN;
+      break;
+    }
+    ctx->hits.resize(out.n_hits);
+    ctx->aux.resize(out.n_hits);
+    if (out.n_hits) {
+      if (hipMemcpyAsync(ctx->hits.data(), out.d_hits, out.n_hits * sizeof(HgHit), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipMemcpyAsync(ctx->aux.data(), out.d_aux, out.n_hits * sizeof(HgHitAux), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        rc = HYPERSCANNER_SCAN;
+        break;
+      }
+    }
+    // deliver line by line; inside a line reports go out by ascending end offset, then id (hs_scan order)
+    size_t i = 0;
+    while (i < ctx->hits.size() && !stop) {
+      size_t j = i;
+      while (j < ctx->hits.size() && ctx->hits[j].line_no == ctx->hits[i].line_no) j++;
+      if (j - i > 1) {
+        std::vector<size_t> order(j - i);
+        for (size_t k = 0; k < order.size(); k++) order[k] = i + k;
+        std::sort(order.begin(), order.end(), [&](size_t x, size_t y) {
+          if (ctx->hits[x].to != ctx->hits[y].to) return ctx->hits[x].to < ctx->hits[y].to;
+          return ctx->hits[x].id < ctx->hits[y].id;
+        });
+        for (size_t k : order) ring.push(ctx->hits[k].id, ctx->hits[k].line_no, ctx->h_buf + ctx->aux[k].start, ctx->aux[k].len);
+      } else {
+        ring.push(ctx->hits[i].id, ctx->hits[i].line_no, ctx->h_buf + ctx->aux[i].start, ctx->aux[i].len);
+      }
+      // the reference checks the limit after each line's hs_scan returns (hyperscanner.c:222-224)
+      if (max_match_count > 0 && ring.delivered >= max_match_count) stop = true;
+      i = j;
+    }
+    line_base += out.n_pieces;
+    std::memmove(ctx->h_buf, ctx->h_buf + cut, have - cut);
+    have -= cut;
+  }
+  ring.flush();
+  return rc;
+}

@@ -28,13 +28,13 @@ void *hgsim_compile(const char *const *exprs, const unsigned *flags, const unsig
   HgDb *db = nullptr;
   std::string e;
   int bad = -1;
-  if (hg_compile(exprs, flags, ids, n, &db, &e, &bad) != 0) {
+  if (hgc_compile(exprs, flags, ids, n, &db, &e, &bad) != 0) {
     if (err && errlen) snprintf(err, errlen, "%d: %s", bad, e.c_str());
     return nullptr;
   }
   return db;
 }
-void hgsim_free(void *h) { hg_db_free(static_cast<HgDb *>(h)); }
+void hgsim_free(void *h) { hgc_free(static_cast<HgDb *>(h)); }
 
 void hgsim_info(void *h, uint32_t *out) {  // npatterns, nfactors, nwindows, nslow, fold_mask, max_nw
   HgDb *db = static_cast<HgDb *>(h);
@@ -80,7 +80,6 @@ long hgsim_scan(void *h, const uint8_t *data, uint64_t nbytes, int buffer_size, 
   HgDbView v = view_of(db);
   if (buffer_size < 2) { *out = nullptr; return 0; }
   uint64_t bs1 = static_cast<uint64_t>(buffer_size) - 1;
-  if (bs1 < HG_TILE_BYTES) return -2;  // small-buffer mode is a separate path
   uint64_t ntiles = (nbytes + HG_TILE_BYTES - 1) / HG_TILE_BYTES;
   std::vector<HgTileSum> sums(ntiles ? ntiles : 1);
   std::vector<HgTileBase> bases(ntiles + 1);
@@ -112,6 +111,9 @@ long hgsim_scan(void *h, const uint8_t *data, uint64_t nbytes, int buffer_size, 
         hg_verify_window(v, data, nbytes, pos, w, [&](uint32_t pattern) { cands.push_back(HgCand{pos, pattern, rank_here}); });
       }
     }
+    s.inner = s.nl_count ? s.nl_count - 1 : 0;
+    if (bs1 < HG_TILE_BYTES && s.nl_count >= 2)  // ~ hg_tile_inner_kernel
+      s.inner = static_cast<uint32_t>(hg_inner_pieces(data, base + s.first_nl + 1, base + s.last_nl + 1, bs1));
     sums[t] = s;
   }
   // ---- tile scan

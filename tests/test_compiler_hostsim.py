@@ -168,3 +168,38 @@ def test_many_patterns_share_windows():
     got, stats, db = sim_hits(data, lits, ids=list(range(len(lits))))
     assert got == want and len(got) > 300
     assert db.info()["nslow"] == 0
+
+
+def test_small_buffer_sizes_match_oracle():
+    rng = random.Random(21)
+    pats = ["needle_in_haystack", "x", "ab+c"]
+    chunks = []
+    for _ in range(300):
+        n = rng.randint(0, 60)
+        line = "".join(rng.choice("abcx _-") for _ in range(n))
+        if rng.random() < 0.2:
+            line += " needle_in_haystack "
+        chunks.append(line.encode() + b"\n")
+    chunks.append(b"y" * 40000 + b"needle_in_haystack" + b"x" * 300 + b"\n")
+    chunks.append(b"tail without newline x")
+    data = b"".join(chunks)
+    for bs in (2, 3, 8, 9, 33, 100, 4097, 16384):
+        for ids in (None, [5, 6, 7]):
+            want, nlines = oracle_hits(data, pats, ids=ids, buffer_size=bs)
+            got, stats, _ = sim_hits(data, pats, ids=ids, buffer_size=bs)
+            assert got == want, (bs, ids)
+            assert stats["pieces"] == nlines, bs
+
+
+def test_golden_plumbing_vectors_through_device_logic():
+    import base64, json, os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "plumbing_vectors.json")) as f:
+        vectors = json.load(f)
+    for v in vectors:
+        if v["data"] is None or "max_match_count" in v["kwargs"]:
+            continue
+        data = base64.b64decode(v["data"])
+        kw = v["kwargs"]
+        got, _, _ = sim_hits(data, v["patterns"], flags=kw.get("flags"), ids=kw.get("ids"), buffer_size=kw.get("buffer_size", 262140))
+        want = sorted((r[0], r[1], base64.b64decode(r[2])) for r in v["rows"])
+        assert sorted((h[0], h[1], data[h[3]:h[3] + h[4]]) for h in got) == want, v["name"]

@@ -1,0 +1,299 @@
+"""GPU parity tests (run on the MI355X box with `-m gpu`): every case goes through the C ABI of
+hypergrep_amd/lib/libhyperscanner.so — Face B `hyperscan()` via the Python API mirror, or the hg_* device-buffer
+API — and is compared bit-exactly with the oracle and the committed golden fixtures.
+
+Nothing here reads /root/reference.
+"""
+from __future__ import annotations
+
+import base64
+import json
+import os
+import random
+
+import pytest
+
+import oracle_py
+import regex_gen
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+FILES = os.path.join(GOLD, "files")
+
+with open(os.path.join(GOLD, "plumbing_vectors.json"), encoding="utf-8") as _f:
+    VECTORS = json.load(_f)
+with open(os.path.join(GOLD, "reference_tables.json"), encoding="utf-8") as _f:
+    TABLES = json.load(_f)
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU: the product has no CPU path to fall back to")
+    return torch
+
+
+def _loaded_native() -> bool:
+    with open("/proc/self/maps", encoding="utf-8") as maps:
+        return "hypergrep_amd/lib/libhyperscanner.so" in maps.read()
+
+
+def gpu_scan_buffer(torch, data: bytes, patterns, flags=None, ids=None, buffer_size=262140, line_base=0):
+    from hypergrep_amd import device
+
+    n = len(data)
+    buf = torch.zeros(n + 32, dtype=torch.uint8, device="cuda:0")
+    if n:
+        buf[:n] = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    db = device.Database(patterns, flags=flags, ids=ids)
+    sc = device.Scanner(db, 0)
+    stats = sc.scan(buf.data_ptr(), n, buffer_size=buffer_size, line_base=line_base)
+    return sorted(sc.hits()), stats
+
+
+def oracle_hits(data, patterns, flags=None, ids=None, buffer_size=262140):
+    rc, hits, nlines = oracle_py.scan_buffer(data, patterns, flags=flags, ids=ids, buffer_size=buffer_size)
+    assert rc == 0
+    return sorted(hits), nlines
+
+
+# ------------------------------------------------------------------ Face B: hyperscan() through the Python API mirror
+@pytest.mark.parametrize("v", [v for v in VECTORS if v["data"] is not None], ids=lambda v: v["name"])
+def test_plumbing_vectors_face_b(torch_cuda, v, tmp_path):
+    import hypergrep_amd
+
+    data = base64.b64decode(v["data"])
+    path = tmp_path / "in.txt"
+    path.write_bytes(data)
+    rows, batches = [], []
+
+    def cb(matches, count):
+        batches.append(count)
+        for i in range(count):
+            rows.append((matches[i].line_number, matches[i].id, matches[i].line))
+
+    rc = hypergrep_amd.scan(str(path), v["patterns"], cb, **v["kwargs"])
+    assert _loaded_native()
+    assert rc == v["rc"]
+    assert rows == [(r[0], r[1], base64.b64decode(r[2])) for r in v["rows"]]
+    assert batches == v["batches"]
+
+
+def test_missing_file_rc6(torch_cuda):
+    import hypergrep_amd
+
+    called = []
+    rc = hypergrep_amd.scan("/nonexistent/definitely/missing", ["x"], lambda m, c: called.append(c))
+    assert rc == 6 and not called
+
+
+@pytest.mark.parametrize("case", TABLES["scan"], ids=lambda c: c["name"])
+def test_reference_table_scan(torch_cuda, case, capsys):
+    import hypergrep_amd
+
+    def cb(matches, count):  # the reference test's _basic_callback (test_hypergrep.py:18-23)
+        for i in range(count):
+            print(f"{matches[i].line_number}:{matches[i].line.decode(errors='ignore').rstrip()}")
+
+    hypergrep_amd.scan(os.path.join(FILES, case["file"]), case["patterns"], cb)
+    assert capsys.readouterr().out.splitlines() == case["returns"]
+
+
+@pytest.mark.parametrize("case", TABLES["grep"], ids=lambda c: c["name"])
+def test_reference_table_grep(torch_cuda, case):
+    import hypergrep_amd
+
+    path = FILES if case["file"] == "." else os.path.join(FILES, case["file"])
+    if "raises" in case:
+        exc = {"FileNotFoundError": FileNotFoundError, "ValueError": ValueError}[case["raises"]]
+        with pytest.raises(exc):
+            hypergrep_amd.grep(path, case["patterns"], **case["kwargs"])
+    else:
+        got = hypergrep_amd.grep(path, case["patterns"], **case["kwargs"])
+        assert [[list(t) for t in got[0]], got[1]] == case["returns"]
+
+
+@pytest.mark.parametrize("case", TABLES["check_compatibility"], ids=lambda c: c["name"])
+def test_reference_table_check(case):
+    import hypergrep_amd
+
+    assert hypergrep_amd.check_compatibility(case["patterns"]) == case["returns"]
+
+
+def test_grep_counts_on_greptest_files(torch_cuda):
+    import hypergrep_amd
+
+    # expectations from the reference's parallel_grep table (test_hypergrep.py:324-418, 553-687)
+    f1 = os.path.join(FILES, "greptest1.txt")
+    assert hypergrep_amd.grep(f1, ["foo"], count_only=True) == (16, 0)
+    assert hypergrep_amd.grep(f1, ["foo"], max_match_count=3) == ([(2, "foo\n"), (3, "foobar\n"), (4, "[foo]\n")], 0)
+    assert hypergrep_amd.grep(f1, ["fOoBaR"]) == ([], 0)
+    assert hypergrep_amd.grep(f1, ["fOoBaR"], ignore_case=True) == ([(3, "foobar\n")], 0)
+    assert hypergrep_amd.grep(f1, ["barfoo\\+"]) == ([(13, "barfoo+\n")], 0)
+    assert hypergrep_amd.grep(f1, ["barfoo+"]) == ([(12, "barfoo\n"), (13, "barfoo+\n")], 0)
+    assert hypergrep_amd.grep(f1, ["foobar", "fo{2}bar", "fo+bar"]) == ([(3, "foobar\n")], 0)
+    assert hypergrep_amd.grep(f1, ["foobar", "extra foo bar"]) == ([(3, "foobar\n"), (16, "extra foo bar\n")], 0)
+    got = hypergrep_amd.grep(f1, ["grep file to test|sync with"], only_matching=True)
+    assert got == ([(1, "grep file to test\n"), (1, "sync with\n"), (18, "grep file to test\n"), (18, "sync with\n")], 0)
+
+
+# ------------------------------------------------------------------ hg_* device-buffer API vs the oracle
+def _log_text(rng, nlines, needles, p_hit=0.2, maxlen=160):
+    words = ["alpha", "beta", "gamma", "delta", "status=200", "user=bob", "GET", "/index.html", "10.0.0.1", "ok",
+             "warn", "retry", "timeout=30", "id=12345", "x", "user=guest status=404"]
+    out = []
+    for _ in range(nlines):
+        n = rng.randint(0, 14)
+        toks = [rng.choice(words) for _ in range(n)]
+        if needles and rng.random() < p_hit:
+            toks.insert(rng.randint(0, len(toks)), rng.choice(needles))
+        out.append(" ".join(toks)[:maxlen])
+    return ("\n".join(out) + "\n").encode()
+
+
+MIXED_PATTERNS = ["needle_in_haystack", "ERR_DISK_FULL_[0-9]{3}", "user=[a-z0-9_]{4,12} status=5[0-9]{2}",
+                  "(?i)caseless_needle", "(first_long_alt|second_long_alt) tail", "connection reset by peer$",
+                  "^kernel panic -", "\\bwordbound_token\\b", "warn", "x$", "[0-9]+\\.[0-9]+\\.[0-9]+"]
+MIXED_NEEDLES = ["needle_in_haystack", "ERR_DISK_FULL_042", "ERR_DISK_FULL_04", "user=alice_01 status=503",
+                 "user=al status=503", "CaseLess_Needle", "first_long_alt tail", "second_long_alt tail",
+                 "second_long_alt  tail", "connection reset by peer", "kernel panic - not syncing", "wordbound_token",
+                 "xwordbound_tokenx", "needle_in_haystac"]
+
+
+@pytest.mark.parametrize("ids_mode", ["shared", "distinct"])
+def test_mixed_tiers_match_oracle(torch_cuda, ids_mode):
+    rng = random.Random(77)
+    data = _log_text(rng, 30000, MIXED_NEEDLES)
+    ids = None if ids_mode == "shared" else list(range(len(MIXED_PATTERNS)))
+    want, nlines = oracle_hits(data, MIXED_PATTERNS, ids=ids)
+    got, stats = gpu_scan_buffer(torch_cuda, data, MIXED_PATTERNS, ids=ids)
+    assert stats.n_lines == nlines
+    assert got == want
+    assert len(want) > 1000
+
+
+def test_tile_boundaries_long_lines_and_buffer_sizes(torch_cuda):
+    rng = random.Random(3)
+    pat = ["needle_in_haystack", "tail_anchor_zz$"]
+    chunks = []
+    for _ in range(60):
+        chunks.append(b"a" * rng.randint(0, 9000) + b" needle_in_haystack " + b"b" * rng.randint(0, 9000) + b" tail_anchor_zz\n")
+    chunks.append(b"q" * 70000 + b"needle_in_haystack" + b"r" * 70000 + b"tail_anchor_zz\n")
+    chunks.append(b"short needle_in_haystack\n")
+    chunks.append(b"no newline at end needle_in_haystack tail_anchor_zz")
+    data = b"".join(chunks)
+    for bs in (262140, 20001, 16385, 16384, 4097, 100, 9):
+        want, nlines = oracle_hits(data, pat, ids=[0, 1], buffer_size=bs)
+        got, stats = gpu_scan_buffer(torch_cuda, data, pat, ids=[0, 1], buffer_size=bs)
+        assert stats.n_lines == nlines, bs
+        assert got == want, bs
+
+
+def test_straddle_every_alignment(torch_cuda):
+    lit = "needle_in_haystack"
+    for shift in range(0, 40, 3):
+        data = b"x" * (16384 - 20 + shift) + lit.encode() + b"\nnext line\n"
+        want, _ = oracle_hits(data, [lit])
+        got, _ = gpu_scan_buffer(torch_cuda, data, [lit])
+        assert got == want and len(got) == 1
+
+
+def test_nul_rules_and_edge_inputs(torch_cuda):
+    pats = ["needle_in_haystack", "x"]
+    data = (b"\0\0needle_in_haystack\n" b"ab\0needle_in_haystack x\n" b"x\0\0\n" b"\0\n" b"needle_in_haystack\0x\n" b"\0\0\0")
+    for ids in (None, [1, 2]):
+        want, nlines = oracle_hits(data, pats, ids=ids)
+        got, stats = gpu_scan_buffer(torch_cuda, data, pats, ids=ids)
+        assert got == want and stats.n_lines == nlines
+    for data in (b"", b"\n", b"x", b"\n\n\n", b"needle_in_haystack"):
+        want, nlines = oracle_hits(data, pats, ids=[1, 2])
+        got, stats = gpu_scan_buffer(torch_cuda, data, pats, ids=[1, 2])
+        assert got == want and stats.n_lines == nlines
+
+
+def test_not_singlematch_and_mixed_ids(torch_cuda):
+    data = b"aaa needle_in_haystack needle_in_haystack\nba\n"
+    pats, flags, ids = ["a", "needle_in_haystack", "needle"], [6, 6, 14], [0, 1, 1]
+    want, _ = oracle_hits(data, pats, flags, ids)
+    got, _ = gpu_scan_buffer(torch_cuda, data, pats, flags, ids)
+    assert got == want
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_patterns_match_oracle(torch_cuda, seed):
+    rng = random.Random(9000 + seed)
+    done = 0
+    for _ in range(12):
+        k = rng.randint(1, 4)
+        pats = [regex_gen.random_pattern(rng) for _ in range(k)]
+        flags = [rng.choice([14, 14, 15, 10, 6, 12]) for _ in range(k)]
+        ids = [rng.randint(0, 2) for _ in range(k)]
+        if oracle_py.check_patterns(pats, flags=flags) != 0:
+            continue
+        data = regex_gen.random_text(rng, 400, final_newline=rng.random() < 0.8)
+        want, nlines = oracle_hits(data, pats, flags, ids)
+        got, stats = gpu_scan_buffer(torch_cuda, data, pats, flags, ids)
+        assert got == want, (pats, flags, ids)
+        assert stats.n_lines == nlines
+        done += 1
+    assert done >= 4
+
+
+def test_many_literals_dense_hits_and_workspace_growth(torch_cuda):
+    rng = random.Random(11)
+    lits = ["tok_%04x_%s" % (i, "".join(rng.choice("abcdef") for _ in range(rng.randint(2, 10)))) for i in range(600)]
+    data = _log_text(rng, 60000, lits, p_hit=0.9)  # ~0.9 hits per line: overflows the initial workspace
+    ids = list(range(len(lits)))
+    want, nlines = oracle_hits(data, lits, ids=ids)
+    got, stats = gpu_scan_buffer(torch_cuda, data, lits, ids=ids)
+    assert stats.n_lines == nlines and got == want
+    assert len(want) > 40000
+
+
+def test_synthetic_log_device_equals_host_and_oracle(torch_cuda):
+    from hypergrep_amd import benchspec, device
+
+    torch = torch_cuda
+    patterns, needles, hpm = benchspec.c3_spec()
+    nbytes = (8 << 20) + 12345  # not a multiple of the generator block nor of the scan tile
+    text = torch.empty(nbytes + 32, dtype=torch.uint8, device="cuda:0")
+    device.synth_device(text.data_ptr(), nbytes, seed=42, needles=needles, hit_per_million=hpm * 4, first_block=5)
+    host = bytes(text[:nbytes].cpu().numpy())
+    assert host == device.synth_host(nbytes, 42, needles, hpm * 4, first_block=5)
+    for ids in (None, list(range(len(patterns)))):
+        db = device.Database(patterns, ids=ids)
+        sc = device.Scanner(db, 0)
+        stats = sc.scan(text.data_ptr(), nbytes, line_base=1000)
+        want, nlines = oracle_hits(host, patterns, ids=ids)
+        assert stats.n_lines == nlines
+        assert sorted(sc.hits()) == sorted((ln + 1000, i, to, off, ln_len) for ln, i, to, off, ln_len in want)
+
+
+def test_large_file_chunked_face_b(torch_cuda, tmp_path, monkeypatch):
+    """hyperscan() with a chunk size far below the file size: chunk cuts, carried line numbers, batching."""
+    import hypergrep_amd
+    from hypergrep_amd import benchspec, device
+
+    patterns, needles, hpm = benchspec.c3_spec()
+    nbytes = 5 << 20
+    host = device.synth_host(nbytes, 9, needles, hpm * 3)
+    host = host[: nbytes - 777]  # last line without '\n'
+    path = tmp_path / "log.txt"
+    path.write_bytes(host)
+    monkeypatch.setenv("HYPERGREP_CHUNK_MB", "1")
+    rows = []
+
+    def cb(matches, count):
+        for i in range(count):
+            rows.append((matches[i].line_number, matches[i].id, matches[i].line))
+
+    ids = list(range(len(patterns)))
+    rc = hypergrep_amd.scan(str(path), patterns, cb, ids=ids, buffer_count=64)
+    assert rc == 0
+    orc, want, _ = oracle_py.scan_file(str(path), patterns, ids=ids, buffer_count=64)
+    assert orc == 0 and rows == want and len(rows) > 500
