@@ -56,8 +56,9 @@ def build(verbose: bool = False, force: bool = False) -> str:
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs + ["-lz", "-ldl", "-Wl,-Bsymbolic", "-Wl,-soname,libhyperscanner.so"]
+    if force or _stale(LIB, objs + [os.path.join(CSRC, "exports.map")]):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs + ["-lz", "-ldl", "-Wl,-Bsymbolic", "-Wl,-soname,libhyperscanner.so",
+                                                                                "-Wl,--version-script=" + os.path.join(CSRC, "exports.map")]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

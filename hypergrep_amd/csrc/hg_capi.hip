@@ -118,6 +118,16 @@ int hg_copy_hits(hg_scanner_t *scanner, hg_hit_t *hits, hg_hit_aux_t *aux, uint6
   return HG_OK;
 }
 
+int hg_copy_hits_device(hg_scanner_t *scanner, void *d_dst, uint64_t max, void *stream) {
+  if (!scanner || !d_dst) return HG_ERR_ARG;
+  uint64_t n = scanner->last.n_hits < max ? scanner->last.n_hits : max;
+  if (!n) return HG_OK;
+  if (hipSetDevice(scanner->sc->device()) != hipSuccess) return HG_ERR_HIP;
+  if (hipMemcpyAsync(d_dst, scanner->last.d_hits, n * sizeof(hg_hit_t), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)) != hipSuccess)
+    return HG_ERR_HIP;
+  return HG_OK;
+}
+
 }  // extern "C"
 
 // ---------------------------------------------------------------- synthetic log

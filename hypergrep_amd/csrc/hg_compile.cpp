@@ -987,10 +987,16 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
       uint32_t fi = static_cast<uint32_t>(db->factors.size());
       db->factors.push_back(fct);
       for (uint32_t res = 0; res < 4; res++) {
-        int best = -1, best_score = INT32_MAX;
+        // the stream kernel checks the window dword and, masked, the dwords before and after it: pick the offset
+        // whose 12-byte neighbourhood [o-4, o+8) covers the most selective bytes of the literal
+        int best = -1, best_sel = -1, best_win = INT32_MAX;
         for (uint32_t o = res; o + 4 <= fct.len; o += 4) {
-          int s = window_score(l, o);
-          if (s < best_score) { best_score = s; best = static_cast<int>(o); }
+          int sel = 0;
+          int lo = static_cast<int>(o) - 4, hi = static_cast<int>(o) + 8;
+          for (int j = std::max(lo, 0); j < std::min<int>(hi, static_cast<int>(fct.len)); j++)
+            sel += 11 - byte_commonness(static_cast<unsigned char>(l.bytes[j]));
+          int win = window_score(l, o);
+          if (sel > best_sel || (sel == best_sel && win < best_win)) { best_sel = sel; best_win = win; best = static_cast<int>(o); }
         }
         if (best < 0) continue;  // cannot happen for len >= 7
         uint32_t v;
@@ -1004,13 +1010,111 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
   }
   std::stable_sort(keyed.begin(), keyed.end(), [](auto &a, auto &b) { return a.first < b.first; });
   db->bucket_off.assign((1u << HG_HASH_BITS) + 1, 0);
-  db->bitmap.assign(HG_BITMAP_WORDS, 0);
   for (auto &kw : keyed) {
     db->bucket_off[kw.first + 1]++;
-    db->bitmap[kw.first >> 5] |= 1u << (kw.first & 31);
     db->windows.push_back(kw.second);
   }
   for (size_t i = 1; i < db->bucket_off.size(); i++) db->bucket_off[i] += db->bucket_off[i - 1];
+  // LDS fingerprint filter: cuckoo placement of the hash of each distinct window value.  Every value
+  // owns exactly one of its two slots, so a lookup that reads both slots can never miss it.
+  {
+    std::vector<uint32_t> values;
+    for (auto &kw : keyed) values.push_back(kw.second.value);
+    std::sort(values.begin(), values.end());
+    values.erase(std::unique(values.begin(), values.end()), values.end());
+    bool placed = false;
+    for (uint32_t attempt = 0; attempt < (HG_FILTER_MAX_LOG2 - HG_FILTER_MIN_LOG2 + 1) * HG_SLOT_WEIGHT_NCHOICES && !placed; attempt++) {
+      // smallest table first; for each size every weight pair
+      const uint32_t k = HG_FILTER_MIN_LOG2 + attempt / HG_SLOT_WEIGHT_NCHOICES;
+      const uint32_t wa = HG_SLOT_WEIGHT_CHOICES[attempt % HG_SLOT_WEIGHT_NCHOICES][0], wb = HG_SLOT_WEIGHT_CHOICES[attempt % HG_SLOT_WEIGHT_NCHOICES][1];
+      if (values.size() * 100 > (size_t(1) << k) * (k == HG_FILTER_MAX_LOG2 ? 49 : 45)) continue;  // keep the load under 45 %
+      const uint32_t byte_mask = ((1u << k) - 1u) << 2;
+      struct Entry { uint32_t sa, sb, fp; };
+      std::vector<Entry> entries;
+      {
+        std::vector<std::array<uint32_t, 3>> keys;  // values with the same slot pair and fingerprint are one entry
+        for (uint32_t v : values) {
+          uint32_t sa = hg_slot(v, wa, byte_mask) >> 2, sb = hg_slot(v, wb, byte_mask) >> 2;
+          keys.push_back({std::min(sa, sb), std::max(sa, sb), hg_hash_window(v)});
+        }
+        std::sort(keys.begin(), keys.end());
+        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+        for (auto &key : keys) entries.push_back({key[0], key[1], key[2]});
+      }
+      std::vector<int32_t> owner(size_t(1) << k, -1);  // entry index owning the slot
+      uint64_t rng = 0x9E3779B97F4A7C15ull;
+      placed = true;
+      for (size_t e = 0; e < entries.size() && placed; e++) {
+        int32_t cur = static_cast<int32_t>(e);
+        bool ok = false;
+        for (int kick = 0; kick < 4000; kick++) {
+          uint32_t sa = entries[cur].sa, sb = entries[cur].sb;
+          if (owner[sa] < 0) { owner[sa] = cur; ok = true; break; }
+          if (owner[sb] < 0) { owner[sb] = cur; ok = true; break; }
+          rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+          uint32_t slot = ((rng >> 33) & 1) ? sa : sb;
+          std::swap(cur, owner[slot]);
+        }
+        if (!ok) placed = false;
+      }
+      if (placed) {
+        db->filter.assign(size_t(1) << k, HG_FILTER_EMPTY);
+        db->ext.assign(size_t(1) << k, HgFilterExt{0, 0, 0, 0});
+        std::vector<bool> seen(size_t(1) << k, false);
+        for (size_t sl = 0; sl < owner.size(); sl++)
+          if (owner[sl] >= 0) db->filter[sl] = entries[owner[sl]].fp;
+        db->filter_log2 = k;
+        db->weights_a = wa;
+        db->weights_b = wb;
+        // neighbour-dword conditions of every window, merged (byte-wise agreement) per owning slot
+        auto merge = [](uint32_t &val, uint32_t &mask, uint32_t v2, uint32_t m2) {
+          uint32_t keep = 0;
+          for (int b = 0; b < 4; b++) {
+            uint32_t bm = 0xFFu << (8 * b);
+            if ((mask & bm) && (m2 & bm) && ((val ^ v2) & bm) == 0) keep |= bm;
+          }
+          mask = keep;
+          val &= keep;
+        };
+        for (auto &kw : keyed) {
+          const HgWindow &w = kw.second;
+          const HgFactor &f = db->factors[w.factor_off >> 8];
+          const int o = static_cast<int>(w.factor_off & 0xff);
+          uint32_t pv = 0, pm = 0, nv = 0, nm = 0;
+          for (int b = 0; b < 4; b++) {
+            int jp = o - 4 + b, jn = o + 4 + b;
+            if (jp >= 0) { pv |= static_cast<uint32_t>(f.lit[jp]) << (8 * b); pm |= 0xFFu << (8 * b); }
+            if (jn < static_cast<int>(f.len)) { nv |= static_cast<uint32_t>(f.lit[jn]) << (8 * b); nm |= 0xFFu << (8 * b); }
+          }
+          pv = (pv | db->fold_mask) & pm;
+          nv = (nv | db->fold_mask) & nm;
+          if (!db->fold_mask) {  // case-insensitive letters cannot be compared exactly without folding: drop them
+            for (int b = 0; b < 4; b++) {
+              int jp = o - 4 + b, jn = o + 4 + b;
+              if (jp >= 0 && f.cmask[jp] != 0xFF) { pm &= ~(0xFFu << (8 * b)); pv &= pm; }
+              if (jn < static_cast<int>(f.len) && f.cmask[jn] != 0xFF) { nm &= ~(0xFFu << (8 * b)); nv &= nm; }
+            }
+          }
+          uint32_t sa = hg_slot(w.value, wa, byte_mask) >> 2, sb = hg_slot(w.value, wb, byte_mask) >> 2;
+          uint32_t fp = hg_hash_window(w.value);
+          // the entry for (sa, sb, fp) sits in exactly one of the two slots
+          for (uint32_t sl : {sa, sb}) {
+            if (owner[sl] < 0) continue;
+            const Entry &e = entries[owner[sl]];
+            if (e.fp != fp || e.sa != std::min(sa, sb) || e.sb != std::max(sa, sb)) continue;
+            HgFilterExt &x = db->ext[sl];
+            if (!seen[sl]) { x = HgFilterExt{pv, pm, nv, nm}; seen[sl] = true; }
+            else { merge(x.pv, x.pm, pv, pm); merge(x.nv, x.nm, nv, nm); }
+          }
+        }
+      }
+    }
+    if (!placed) {
+      if (err) *err = "too many distinct literal windows for the LDS filter";
+      if (bad_index) *bad_index = -1;
+      return -4;
+    }
+  }
   if (db->windows.empty()) db->windows.push_back(HgWindow{0, 0});  // keep device arrays non-empty
   if (db->factors.empty()) db->factors.push_back(HgFactor{});
   *out = db.release();

@@ -13,7 +13,10 @@ struct HgDb {
   std::vector<HgFactor> factors;     // required literals of tier-0 patterns
   std::vector<HgWindow> windows;     // grouped by bucket
   std::vector<uint32_t> bucket_off;  // (1 << HG_HASH_BITS) + 1 offsets into windows
-  std::vector<uint32_t> bitmap;      // HG_BITMAP_WORDS: bucket non-empty bits (staged in LDS by the stream kernel)
+  std::vector<uint32_t> filter;      // 1 << filter_log2 slots holding hash C of the owning window (staged in LDS by the stream kernel)
+  uint32_t filter_log2 = HG_FILTER_MIN_LOG2;
+  uint32_t weights_a = HG_SLOT_WEIGHT_CHOICES[0][0], weights_b = HG_SLOT_WEIGHT_CHOICES[0][1];
+  std::vector<HgFilterExt> ext;      // per filter slot: neighbour-dword conditions (second-level check)
   std::vector<uint32_t> slow;        // indices of tier-1 (always-on) patterns
   uint32_t fold_mask = 0;            // 0x20202020 when any tier-0 pattern is case-insensitive
   uint32_t max_nw = 1;

@@ -24,10 +24,11 @@ struct HgTileBase {
   uint64_t cs;  // absolute start of the line that is open at the tile start ("carry-in" line)
   uint64_t L;   // piece index (= reference line_number) of the piece starting at cs
 };
-// A verified required-literal occurrence: pattern `pattern` may match in the line containing byte `pos`.
+// A window-filter hit from the stream pass: the dword `word` at byte `pos` has the fingerprint of some
+// pattern's required-literal window (not yet compared with the literal itself).
 struct HgCand {
   uint64_t pos;
-  uint32_t pattern;
+  uint32_t word;
   uint32_t rank;  // '\n' bytes in [tile start, pos)
 };
 // Final records (16 B + 16 B): one per (line piece, report).

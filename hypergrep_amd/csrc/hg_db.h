@@ -28,8 +28,24 @@ constexpr uint32_t HG_MAX_W = HG_MAX_NODES / 32;
 constexpr uint32_t HG_FACTOR_MAX = 32;   // bytes of a required literal kept for the in-stream verify
 constexpr uint32_t HG_FAST_MIN_FACTOR = 7;  // 4-byte window on every residue mod 4 needs length >= 7
 constexpr uint32_t HG_HASH_BITS = 18;       // v_dot4_u32_u8 of four bytes with weights < 256 fits 18 bits
-constexpr uint32_t HG_BITMAP_WORDS = (1u << HG_HASH_BITS) / 32;  // 8192 words = 32 KiB of LDS
-constexpr uint32_t HG_HASH_WEIGHTS = 0xfbf1efe9u;  // byte weights 233, 239, 241, 251 (distinct primes)
+// Three byte-weighted sums of the (case-folded) window dword, one v_dot4_u32_u8 each:
+//   hash C  -> bucket index of the window table in HBM, and (low 16 bits) the fingerprint
+//   hash A/B (weights are multiples of 4, so the sum is already the byte offset of a 4-byte slot) -> the two
+//   candidate slots of the window in the LDS filter (cuckoo placement: every window sits in exactly one of them).
+// A slot holds the window's full hash C (18 bits) in a dword: sub-dword LDS reads (ds_read_u16) measured ~8x
+// slower than ds_read_b32 on gfx950 for this random-access pattern.
+constexpr uint32_t HG_HASH_WEIGHTS = 0xfbf1efe9u;    // C: 233, 239, 241, 251
+// A / B weight pairs the compiler tries in turn until the cuckoo placement succeeds (bytes are multiples of 4
+// and deliberately not in arithmetic progression, so that no small byte difference cancels in both sums).
+constexpr uint32_t HG_SLOT_WEIGHT_CHOICES[][2] = {
+    {0x2cec94fcu, 0xbc34f474u},  // A: 252,148,236,44   B: 116,244,52,188
+    {0x74d43cb4u, 0xe40c9c5cu},  // A: 180,60,212,116   B: 92,156,12,228
+    {0xa41cf86cu, 0x54c4247cu},  // A: 108,248,28,164   B: 124,36,196,84
+    {0xdc4484f4u, 0x1cac6cccu},  // A: 244,132,68,220   B: 204,108,172,28
+};
+constexpr uint32_t HG_SLOT_WEIGHT_NCHOICES = 4;
+constexpr uint32_t HG_FILTER_MIN_LOG2 = 11, HG_FILTER_MAX_LOG2 = 15;  // 4-byte slots: 8 KiB .. 128 KiB of LDS
+constexpr uint32_t HG_FILTER_EMPTY = 0xFFFFFFFFu;
 
 // One compiled expression: a position (Glushkov) automaton whose nodes are (position, entry condition).
 // Tables live in one u32 pool; *_off are indices into it.
@@ -65,13 +81,25 @@ struct HgWindow {
   uint32_t factor_off;  // factor index << 8 | off
 };
 
-HG_HD uint32_t hg_hash_window(uint32_t folded) {
+HG_HD uint32_t hg_dot4(uint32_t v, uint32_t w) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  return __builtin_amdgcn_udot4(folded, HG_HASH_WEIGHTS, 0u, false);
+  return __builtin_amdgcn_udot4(v, w, 0u, false);
 #else
-  return (folded & 0xff) * (HG_HASH_WEIGHTS & 0xff) + ((folded >> 8) & 0xff) * ((HG_HASH_WEIGHTS >> 8) & 0xff) +
-         ((folded >> 16) & 0xff) * ((HG_HASH_WEIGHTS >> 16) & 0xff) + (folded >> 24) * (HG_HASH_WEIGHTS >> 24);
+  return (v & 0xff) * (w & 0xff) + ((v >> 8) & 0xff) * ((w >> 8) & 0xff) + ((v >> 16) & 0xff) * ((w >> 16) & 0xff) + (v >> 24) * (w >> 24);
 #endif
+}
+HG_HD uint32_t hg_hash_window(uint32_t folded) { return hg_dot4(folded, HG_HASH_WEIGHTS); }
+// Byte offsets of the two candidate slots; byte_mask = (slots - 1) << 2.
+HG_HD uint32_t hg_slot(uint32_t folded, uint32_t weights, uint32_t byte_mask) { return hg_dot4(folded, weights) & byte_mask; }
+
+// Second-level check of a filter slot: what the dwords just before / after the window must look like
+// (folded, byte-masked) for any of the slot's windows to be part of its literal.  Conservative union.
+struct HgFilterExt {
+  uint32_t pv, pm;  // previous dword: (prev | fold) & pm == pv
+  uint32_t nv, nm;  // next dword
+};
+HG_HD bool hg_ext_pass(const HgFilterExt &e, uint32_t prev_folded, uint32_t next_folded) {
+  return (((prev_folded ^ e.pv) & e.pm) | ((next_folded ^ e.nv) & e.nm)) == 0;
 }
 
 HG_HD bool hg_is_word(uint32_t b) {

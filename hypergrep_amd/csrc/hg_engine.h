@@ -9,16 +9,20 @@
 #include "hg_core.h"
 #include "hg_post.h"
 
-enum { HG_CNT_CANDS = 0, HG_CNT_HITS = 1, HG_CNT_WORDS = 8 };
+// device counters: totals, and the largest per-segment demand seen when a private segment overflowed
+enum { HG_CNT_CANDS = 0, HG_CNT_HITS = 1, HG_CNT_CAND_NEED = 2, HG_CNT_HIT_NEED = 3, HG_CNT_WORDS = 8 };
 
 struct HgStreamArgs {
   const uint8_t *text;
   uint64_t nbytes, ntiles;
   HgDbView db;
-  const uint32_t *bitmap;
+  const uint32_t *filter;  // 1 << filter_log2 window-hash slots
+  const HgFilterExt *ext;  // per slot: neighbour-dword conditions
   HgTileSum *sums;
-  HgCand *cands;
-  uint32_t cand_cap, pad;
+  HgCand *cands;         // nsegs x cand_seg_cap: one private segment per stream workgroup
+  uint32_t *seg_count;   // candidates in each segment
+  uint32_t cand_seg_cap, filter_log2;
+  uint32_t weights_a, weights_b;
   uint32_t *counters;
 };
 
@@ -29,9 +33,12 @@ struct HgConfirmArgs {
   const HgTileSum *sums;
   const HgTileBase *bases;
   const HgCand *cands;
-  HgHit *hits;
+  const uint32_t *seg_count;
+  HgHit *hits;  // compact outputs
   HgHitAux *aux;
-  uint32_t cand_cap, hit_cap;
+  HgHit *tmp_hits;  // gridDim x hit_seg_cap block-private staging
+  HgHitAux *tmp_aux;
+  uint32_t cand_seg_cap, hit_cap, hit_seg_cap, pad;
   uint32_t *counters;
 };
 
@@ -53,23 +60,30 @@ class HgScanner {
   ~HgScanner();
   // d_text: device pointer, 16-byte aligned, readable up to nbytes rounded up to 16.
   int scan(const void *d_text, uint64_t nbytes, int buffer_size, uint64_t line_base, hipStream_t stream, HgScanOutput *out);
+  // Block mode (hs_scan): the whole buffer is one scan unit; hits carry line_no 0 and `to` relative to the buffer start.
+  int scan_block(const void *d_text, uint64_t nbytes, hipStream_t stream, HgScanOutput *out);
   const std::string &last_error() const { return err_; }
   int device() const { return device_; }
 
  private:
   HgScanner() = default;
   int ensure(uint64_t nbytes);
-  int run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint64_t line_base, hipStream_t stream, HgScanOutput *out, bool *overflow);
+  int alloc_cands(uint64_t n);
+  int alloc_hits(uint64_t n);
+  int scan_impl(const void *d_text, uint64_t nbytes, int buffer_size, uint64_t line_base, bool block_mode, hipStream_t stream, HgScanOutput *out);
+  int run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint64_t line_base, bool block_mode, hipStream_t stream, HgScanOutput *out,
+               bool *overflow);
   bool fail(hipError_t e, const char *what);
 
   int device_ = 0;
   int num_cus_ = 256;
+  int stream_wgs_per_cu_ = 0;
   std::string err_;
   // database on device
   HgDbView view_{};
   const HgDb *db_ = nullptr;
   void *d_patterns_ = nullptr, *d_pool_ = nullptr, *d_factors_ = nullptr, *d_windows_ = nullptr, *d_bucket_ = nullptr,
-       *d_bitmap_ = nullptr, *d_slow_ = nullptr;
+       *d_filter_ = nullptr, *d_ext_ = nullptr, *d_slow_ = nullptr;
   // workspace
   uint64_t cap_tiles_ = 0;
   uint32_t cand_cap_ = 0, hit_cap_ = 0;
@@ -82,7 +96,9 @@ class HgScanner {
   uint64_t *d_key_a_ = nullptr, *d_key_b_ = nullptr;
   uint32_t *d_perm_a_ = nullptr, *d_perm_b_ = nullptr;
   uint8_t *d_keep_ = nullptr;
-  uint32_t *d_counters_ = nullptr, *d_selected_ = nullptr;
+  uint32_t *d_counters_ = nullptr, *d_selected_ = nullptr, *d_seg_count_ = nullptr;
+  uint32_t max_segs_ = 0;
+  uint32_t *d_pflags_ = nullptr;
   void *d_temp_ = nullptr;
   size_t temp_bytes_ = 0;
   uint32_t *h_counters_ = nullptr;  // pinned

@@ -12,7 +12,8 @@
 #include <rocprim/rocprim.hpp>
 
 // kernels (hg_kernels.hip)
-__global__ void hg_stream_kernel(HgStreamArgs a);
+void hg_launch_stream(const HgStreamArgs &a, uint32_t grid, hipStream_t stream);
+int hg_stream_blocks_per_cu(uint32_t filter_log2);
 __global__ void hg_tile_reduce_kernel(const HgTileSum *sums, uint64_t ntiles, uint64_t bs1, HgTileElem *agg);
 __global__ void hg_tile_spine_kernel(const HgTileElem *agg, uint32_t nblocks, uint64_t bs1, HgTileBase init, HgTileBase *block_base,
                                      HgTileBase *final_state);
@@ -20,6 +21,8 @@ __global__ void hg_tile_apply_kernel(const HgTileSum *sums, uint64_t ntiles, uin
 __global__ void hg_tile_inner_kernel(const uint8_t *text, HgTileSum *sums, uint64_t ntiles, uint64_t bs1);
 __global__ void hg_confirm_kernel(HgConfirmArgs a);
 __global__ void hg_always_on_kernel(HgConfirmArgs a);
+__global__ void hg_block_mark_kernel(HgConfirmArgs a, uint32_t *pattern_flags);
+__global__ void hg_block_scan_kernel(HgConfirmArgs a, const uint32_t *pattern_flags);
 __global__ void hg_key_kernel(const HgHit *hits, const HgHitAux *aux, const HgPattern *patterns, uint32_t n, uint64_t *key, uint32_t *idx);
 __global__ void hg_line_key_kernel(const HgHit *hits, const uint32_t *perm, uint32_t n, uint64_t *key);
 __global__ void hg_gather_kernel(const HgHit *hits, const HgHitAux *aux, const uint32_t *perm, uint32_t n, HgHit *oh, HgHitAux *oa);
@@ -27,7 +30,7 @@ __global__ void hg_keep_kernel(const HgHit *hits, const HgHitAux *aux, const HgP
 
 namespace {
 constexpr int TS_BLOCK_TILES = 1024;  // must match hg_kernels.hip (256 threads x 4 tiles)
-constexpr int STREAM_WG_WAVES = 8;
+constexpr int STREAM_WG_WAVES = 8;  // must match hg_kernels.hip
 
 template <typename T>
 hipError_t upload(void **dst, const std::vector<T> &src) {
@@ -79,7 +82,8 @@ int HgScanner::create(const HgDb *db, int device, HgScanner **out, std::string *
   HG_TRY(upload(&s->d_factors_, db->factors), "upload factors");
   HG_TRY(upload(&s->d_windows_, db->windows), "upload windows");
   HG_TRY(upload(&s->d_bucket_, db->bucket_off), "upload buckets");
-  HG_TRY(upload(&s->d_bitmap_, db->bitmap), "upload bitmap");
+  HG_TRY(upload(&s->d_filter_, db->filter), "upload filter");
+  HG_TRY(upload(&s->d_ext_, db->ext), "upload filter conditions");
   HG_TRY(upload(&s->d_slow_, db->slow), "upload always-on list");
   s->view_.patterns = static_cast<const HgPattern *>(s->d_patterns_);
   s->view_.pool = static_cast<const uint32_t *>(s->d_pool_);
@@ -93,6 +97,7 @@ int HgScanner::create(const HgDb *db, int device, HgScanner **out, std::string *
   HG_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_counters_), HG_CNT_WORDS * 4), "alloc counters");
   HG_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_selected_), 16), "alloc counters");
   HG_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_final_), sizeof(HgTileBase)), "alloc state");
+  HG_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_pflags_), db->patterns.size() * 4 + 16), "alloc pattern flags");
   HG_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_counters_), (HG_CNT_WORDS + 4) * 4), "alloc pinned");
   HG_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_final_), sizeof(HgTileBase)), "alloc pinned");
   for (auto &ev : s->ev_) HG_TRY(hipEventCreate(&ev), "hipEventCreate");
@@ -103,15 +108,48 @@ int HgScanner::create(const HgDb *db, int device, HgScanner **out, std::string *
 
 HgScanner::~HgScanner() {
   (void)hipSetDevice(device_);
-  void *ptrs[] = {d_patterns_, d_pool_, d_factors_, d_windows_, d_bucket_, d_bitmap_, d_slow_, d_sums_, d_bases_, d_block_base_,
+  void *ptrs[] = {d_patterns_, d_pool_, d_factors_, d_windows_, d_bucket_, d_filter_, d_ext_, d_slow_, d_sums_, d_bases_, d_block_base_,
                   d_final_, d_agg_, d_cands_, d_hits_raw_, d_hits_sorted_, d_hits_out_, d_aux_raw_, d_aux_sorted_, d_aux_out_,
-                  d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, d_keep_, d_counters_, d_selected_, d_temp_};
+                  d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, d_keep_, d_counters_, d_selected_, d_temp_, d_seg_count_, d_pflags_};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (h_counters_) (void)hipHostFree(h_counters_);
   if (h_final_) (void)hipHostFree(h_final_);
   for (auto &ev : ev_)
     if (ev) (void)hipEventDestroy(ev);
+}
+
+int HgScanner::alloc_cands(uint64_t n) {
+  n = std::min<uint64_t>(n, 0x7FFFFFF0u);
+  if (d_cands_) (void)hipFree(d_cands_);
+  d_cands_ = nullptr;
+  if (fail(hipMalloc(reinterpret_cast<void **>(&d_cands_), n * sizeof(HgCand)), "workspace alloc (candidates)")) return HG_ERR_HIP;
+  cand_cap_ = static_cast<uint32_t>(n);
+  return HG_OK;
+}
+
+int HgScanner::alloc_hits(uint64_t n64) {
+  const uint32_t n = static_cast<uint32_t>(std::min<uint64_t>(n64, 0x7FFFFFF0u));
+  auto re = [&](auto *&ptr, size_t count) -> bool {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    return fail(hipMalloc(reinterpret_cast<void **>(&ptr), std::max<size_t>(count * sizeof(*ptr), 16)), "workspace alloc (hits)");
+  };
+  if (re(d_hits_raw_, n) || re(d_hits_sorted_, n) || re(d_hits_out_, n) || re(d_aux_raw_, n) || re(d_aux_sorted_, n) || re(d_aux_out_, n) ||
+      re(d_key_a_, n) || re(d_key_b_, n) || re(d_perm_a_, n) || re(d_perm_b_, n) || re(d_keep_, n))
+    return HG_ERR_HIP;
+  hit_cap_ = n;
+  size_t t1 = 0, t2 = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, t1, d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, n, 0, 64, hipStream_t(nullptr));
+  (void)rocprim::select(nullptr, t2, d_hits_sorted_, d_keep_, d_hits_out_, d_selected_, n, hipStream_t(nullptr));
+  size_t need = std::max(t1, t2) + 256;
+  if (need > temp_bytes_) {
+    if (d_temp_) (void)hipFree(d_temp_);
+    d_temp_ = nullptr;
+    if (fail(hipMalloc(&d_temp_, need), "workspace alloc (sort)")) return HG_ERR_HIP;
+    temp_bytes_ = need;
+  }
+  return HG_OK;
 }
 
 int HgScanner::ensure(uint64_t nbytes) {
@@ -126,35 +164,19 @@ int HgScanner::ensure(uint64_t nbytes) {
     if (re(d_sums_, ntiles) || re(d_bases_, ntiles + 1) || re(d_agg_, nblocks) || re(d_block_base_, nblocks)) return HG_ERR_HIP;
     cap_tiles_ = ntiles;
   }
-  // one candidate / hit per KiB of text to start with; grows on overflow
+  if (!d_seg_count_) {
+    max_segs_ = static_cast<uint32_t>(num_cus_) * 16;
+    if (re(d_seg_count_, max_segs_)) return HG_ERR_HIP;
+  }
+  // one candidate / hit per KiB of text to start with; grows (and the pass repeats) on overflow
   uint64_t want = std::max<uint64_t>(nbytes / 1024, 1u << 16);
-  want = std::min<uint64_t>(want, 0x7FFFFFF0u);
-  if (cand_cap_ < want) {
-    if (re(d_cands_, want)) return HG_ERR_HIP;
-    cand_cap_ = static_cast<uint32_t>(want);
-  }
-  if (hit_cap_ < want) {
-    uint32_t n = static_cast<uint32_t>(want);
-    if (re(d_hits_raw_, n) || re(d_hits_sorted_, n) || re(d_hits_out_, n) || re(d_aux_raw_, n) || re(d_aux_sorted_, n) ||
-        re(d_aux_out_, n) || re(d_key_a_, n) || re(d_key_b_, n) || re(d_perm_a_, n) || re(d_perm_b_, n) || re(d_keep_, n))
-      return HG_ERR_HIP;
-    hit_cap_ = n;
-    size_t t1 = 0, t2 = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, t1, d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, n, 0, 64, hipStream_t(nullptr));
-    (void)rocprim::select(nullptr, t2, d_hits_sorted_, d_keep_, d_hits_out_, d_selected_, n, hipStream_t(nullptr));
-    size_t need = std::max(t1, t2) + 256;
-    if (need > temp_bytes_) {
-      if (d_temp_) (void)hipFree(d_temp_);
-      d_temp_ = nullptr;
-      if (fail(hipMalloc(&d_temp_, need), "workspace alloc")) return HG_ERR_HIP;
-      temp_bytes_ = need;
-    }
-  }
+  if (cand_cap_ < want && alloc_cands(want)) return HG_ERR_HIP;
+  if (hit_cap_ < want && alloc_hits(want)) return HG_ERR_HIP;
   return HG_OK;
 }
 
-int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint64_t line_base, hipStream_t stream, HgScanOutput *out,
-                        bool *overflow) {
+int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint64_t line_base, bool block_mode, hipStream_t stream,
+                        HgScanOutput *out, bool *overflow) {
   *overflow = false;
   const uint64_t ntiles = (nbytes + HG_TILE_BYTES - 1) / HG_TILE_BYTES;
   const uint32_t nblocks = static_cast<uint32_t>((ntiles + TS_BLOCK_TILES - 1) / TS_BLOCK_TILES);
@@ -163,32 +185,42 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   HG_TRY(hipMemsetAsync(d_counters_, 0, HG_CNT_WORDS * 4, stream), "memset counters");
   HG_TRY(hipEventRecord(ev_[0], stream), "event");
 
-  HgStreamArgs sa{};
-  sa.text = text;
-  sa.nbytes = nbytes;
-  sa.ntiles = ntiles;
-  sa.db = view_;
-  sa.bitmap = static_cast<const uint32_t *>(d_bitmap_);
-  sa.sums = d_sums_;
-  sa.cands = d_cands_;
-  sa.cand_cap = cand_cap_;
-  sa.counters = d_counters_;
+  uint32_t wgs = 1, confirm_blocks = 1, always_blocks = 1;
   if (ntiles) {
-    uint32_t wgs = static_cast<uint32_t>(std::min<uint64_t>((ntiles + STREAM_WG_WAVES - 1) / STREAM_WG_WAVES, static_cast<uint64_t>(num_cus_) * 2));
+    if (stream_wgs_per_cu_ == 0) stream_wgs_per_cu_ = hg_stream_blocks_per_cu(db_->filter_log2);
+    wgs = static_cast<uint32_t>(std::min<uint64_t>((ntiles + STREAM_WG_WAVES - 1) / STREAM_WG_WAVES,
+                                                   std::min<uint64_t>(static_cast<uint64_t>(num_cus_) * stream_wgs_per_cu_, max_segs_)));
+    HgStreamArgs sa{};
+    sa.text = text;
+    sa.nbytes = nbytes;
+    sa.ntiles = ntiles;
+    sa.db = view_;
+    sa.filter = static_cast<const uint32_t *>(d_filter_);
+    sa.filter_log2 = db_->filter_log2;
+    sa.weights_a = db_->weights_a;
+    sa.weights_b = db_->weights_b;
+    sa.ext = static_cast<const HgFilterExt *>(d_ext_);
+    sa.sums = d_sums_;
+    sa.cands = d_cands_;
+    sa.seg_count = d_seg_count_;
+    sa.cand_seg_cap = cand_cap_ / wgs;
+    sa.counters = d_counters_;
     HG_TRY(hipEventRecord(ev_[1], stream), "event");
-    hipLaunchKernelGGL(hg_stream_kernel, dim3(wgs), dim3(STREAM_WG_WAVES * 64), 0, stream, sa);
+    hg_launch_stream(sa, wgs, stream);
     HG_TRY(hipGetLastError(), "hg_stream_kernel launch");
     HG_TRY(hipEventRecord(ev_[2], stream), "event");
 
-    if (bs1 < HG_TILE_BYTES) {  // small-buffer mode: lines inside a tile can split, re-price the tile summaries
-      uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((ntiles + 255) / 256, 4096));
-      hipLaunchKernelGGL(hg_tile_inner_kernel, dim3(blocks), dim3(256), 0, stream, text, d_sums_, ntiles, bs1);
+    if (!block_mode) {
+      if (bs1 < HG_TILE_BYTES) {  // small-buffer mode: lines inside a tile can split, re-price the tile summaries
+        uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((ntiles + 255) / 256, 4096));
+        hipLaunchKernelGGL(hg_tile_inner_kernel, dim3(blocks), dim3(256), 0, stream, text, d_sums_, ntiles, bs1);
+      }
+      HgTileBase init{0, line_base};
+      hipLaunchKernelGGL(hg_tile_reduce_kernel, dim3(nblocks), dim3(256), 0, stream, d_sums_, ntiles, bs1, d_agg_);
+      hipLaunchKernelGGL(hg_tile_spine_kernel, dim3(1), dim3(256), 0, stream, d_agg_, nblocks, bs1, init, d_block_base_, d_final_);
+      hipLaunchKernelGGL(hg_tile_apply_kernel, dim3(nblocks), dim3(256), 0, stream, d_sums_, ntiles, bs1, d_block_base_, d_bases_);
+      HG_TRY(hipGetLastError(), "tile scan launch");
     }
-    HgTileBase init{0, line_base};
-    hipLaunchKernelGGL(hg_tile_reduce_kernel, dim3(nblocks), dim3(256), 0, stream, d_sums_, ntiles, bs1, d_agg_);
-    hipLaunchKernelGGL(hg_tile_spine_kernel, dim3(1), dim3(256), 0, stream, d_agg_, nblocks, bs1, init, d_block_base_, d_final_);
-    hipLaunchKernelGGL(hg_tile_apply_kernel, dim3(nblocks), dim3(256), 0, stream, d_sums_, ntiles, bs1, d_block_base_, d_bases_);
-    HG_TRY(hipGetLastError(), "tile scan launch");
 
     HgConfirmArgs ca{};
     ca.text = text;
@@ -199,21 +231,34 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
     ca.sums = d_sums_;
     ca.bases = d_bases_;
     ca.cands = d_cands_;
+    ca.seg_count = d_seg_count_;
     ca.hits = d_hits_raw_;
     ca.aux = d_aux_raw_;
-    ca.cand_cap = cand_cap_;
+    ca.tmp_hits = d_hits_out_;  // free until the final select
+    ca.tmp_aux = d_aux_out_;
+    ca.cand_seg_cap = sa.cand_seg_cap;
     ca.hit_cap = hit_cap_;
     ca.counters = d_counters_;
-    if (db_->patterns.size() > db_->slow.size()) {
-      hipLaunchKernelGGL(hg_confirm_kernel, dim3(static_cast<uint32_t>(num_cus_) * 8), dim3(256), 0, stream, ca);
+    if (block_mode) {
+      HG_TRY(hipMemsetAsync(d_pflags_, 0, db_->patterns.size() * 4, stream), "memset pattern flags");
+      if (db_->patterns.size() > db_->slow.size()) hipLaunchKernelGGL(hg_block_mark_kernel, dim3(wgs), dim3(256), 0, stream, ca, d_pflags_);
+      always_blocks = static_cast<uint32_t>((db_->patterns.size() + 255) / 256);
+      ca.hit_seg_cap = hit_cap_ / always_blocks;
+      hipLaunchKernelGGL(hg_block_scan_kernel, dim3(always_blocks), dim3(256), 0, stream, ca, d_pflags_);
+      HG_TRY(hipGetLastError(), "block-mode launch");
+    } else if (db_->patterns.size() > db_->slow.size()) {
+      confirm_blocks = wgs;  // block b consumes candidate segment b
+      ca.hit_seg_cap = hit_cap_ / confirm_blocks;
+      hipLaunchKernelGGL(hg_confirm_kernel, dim3(confirm_blocks), dim3(256), 0, stream, ca);
       HG_TRY(hipGetLastError(), "hg_confirm_kernel launch");
     }
-    if (!db_->slow.empty()) {
-      uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((ntiles + 3) / 4, static_cast<uint64_t>(num_cus_) * 8));
-      hipLaunchKernelGGL(hg_always_on_kernel, dim3(blocks), dim3(256), 0, stream, ca);
+    if (!block_mode && !db_->slow.empty()) {
+      always_blocks = static_cast<uint32_t>(std::min<uint64_t>((ntiles + 3) / 4, static_cast<uint64_t>(num_cus_) * 8));
+      ca.hit_seg_cap = hit_cap_ / always_blocks;
+      hipLaunchKernelGGL(hg_always_on_kernel, dim3(always_blocks), dim3(256), 0, stream, ca);
       HG_TRY(hipGetLastError(), "hg_always_on_kernel launch");
     }
-    HG_TRY(hipMemcpyAsync(h_final_, d_final_, sizeof(HgTileBase), hipMemcpyDeviceToHost, stream), "copy state");
+    if (!block_mode) HG_TRY(hipMemcpyAsync(h_final_, d_final_, sizeof(HgTileBase), hipMemcpyDeviceToHost, stream), "copy state");
   } else {
     HG_TRY(hipEventRecord(ev_[1], stream), "event");
     HG_TRY(hipEventRecord(ev_[2], stream), "event");
@@ -224,45 +269,33 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   HG_TRY(hipStreamSynchronize(stream), "stream sync (scan kernels)");
 
   const uint64_t n_cands = h_counters_[HG_CNT_CANDS], n_raw = h_counters_[HG_CNT_HITS];
-  if (n_cands > cand_cap_ || n_raw > hit_cap_) {
-    // grow and let the caller repeat the pass: nothing is dropped silently
-    uint64_t want_c = std::min<uint64_t>(std::max<uint64_t>(n_cands + n_cands / 4, cand_cap_), 0x7FFFFFF0u);
-    uint64_t want_h = std::min<uint64_t>(std::max<uint64_t>(std::max(n_raw, n_cands) * 5 / 4, hit_cap_), 0x7FFFFFF0u);
-    if ((n_cands > cand_cap_ && want_c <= cand_cap_) || (n_raw > hit_cap_ && want_h <= hit_cap_)) {
-      err_ = "more than 2^31 candidates in one scan call: split the buffer";
-      return HG_ERR_ARG;
-    }
-    auto grow = [&](auto *&ptr, size_t count) {
-      if (ptr) (void)hipFree(ptr);
-      ptr = nullptr;
-      return fail(hipMalloc(reinterpret_cast<void **>(&ptr), count * sizeof(*ptr)), "workspace grow");
-    };
-    if (want_c > cand_cap_) {
-      if (grow(d_cands_, want_c)) return HG_ERR_HIP;
-      cand_cap_ = static_cast<uint32_t>(want_c);
-    }
-    if (want_h > hit_cap_) {
-      uint32_t n = static_cast<uint32_t>(want_h);
-      if (grow(d_hits_raw_, n) || grow(d_hits_sorted_, n) || grow(d_hits_out_, n) || grow(d_aux_raw_, n) || grow(d_aux_sorted_, n) ||
-          grow(d_aux_out_, n) || grow(d_key_a_, n) || grow(d_key_b_, n) || grow(d_perm_a_, n) || grow(d_perm_b_, n) || grow(d_keep_, n))
-        return HG_ERR_HIP;
-      hit_cap_ = n;
-      size_t t1 = 0, t2 = 0;
-      (void)rocprim::radix_sort_pairs(nullptr, t1, d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, n, 0, 64, hipStream_t(nullptr));
-      (void)rocprim::select(nullptr, t2, d_hits_sorted_, d_keep_, d_hits_out_, d_selected_, n, hipStream_t(nullptr));
-      size_t need = std::max(t1, t2) + 256;
-      if (need > temp_bytes_) {
-        if (d_temp_) (void)hipFree(d_temp_);
-        d_temp_ = nullptr;
-        if (fail(hipMalloc(&d_temp_, need), "workspace grow")) return HG_ERR_HIP;
-        temp_bytes_ = need;
+  const uint64_t cand_need = h_counters_[HG_CNT_CAND_NEED], hit_need = h_counters_[HG_CNT_HIT_NEED];
+  if (cand_need || hit_need || n_raw > hit_cap_) {
+    // a private segment (or the compact hit array) was too small: grow and let the caller repeat the pass
+    if (cand_need) {
+      uint64_t want = (cand_need + cand_need / 4 + 64) * wgs;
+      if (want > 0x7FFFFFF0u) {
+        err_ = "more than 2^31 candidates in one scan call: split the buffer";
+        return HG_ERR_ARG;
       }
+      int rc = alloc_cands(want);
+      if (rc) return rc;
+    }
+    if (hit_need || n_raw > hit_cap_) {
+      uint64_t want = std::max<uint64_t>((hit_need + hit_need / 4 + 64) * std::max(confirm_blocks, always_blocks), n_raw + n_raw / 4);
+      want = std::max<uint64_t>(want, static_cast<uint64_t>(hit_cap_) * 2);
+      if (want > 0x7FFFFFF0u) {
+        err_ = "more than 2^31 hits in one scan call: split the buffer";
+        return HG_ERR_ARG;
+      }
+      int rc = alloc_hits(want);
+      if (rc) return rc;
     }
     *overflow = true;
     return HG_OK;
   }
 
-  uint64_t n_pieces = h_final_->L - line_base + (nbytes > h_final_->cs ? hg_pieces(nbytes - h_final_->cs, bs1) : 0);
+  uint64_t n_pieces = block_mode ? 1 : h_final_->L - line_base + (nbytes > h_final_->cs ? hg_pieces(nbytes - h_final_->cs, bs1) : 0);
   uint32_t n = static_cast<uint32_t>(n_raw);
   uint32_t kept = 0;
   if (n) {
@@ -301,7 +334,16 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   return HG_OK;
 }
 
+int HgScanner::scan_block(const void *d_text, uint64_t nbytes, hipStream_t stream, HgScanOutput *out) {
+  return scan_impl(d_text, nbytes, 0x7FFFFFFF, 0, true, stream, out);
+}
+
 int HgScanner::scan(const void *d_text, uint64_t nbytes, int buffer_size, uint64_t line_base, hipStream_t stream, HgScanOutput *out) {
+  return scan_impl(d_text, nbytes, buffer_size, line_base, false, stream, out);
+}
+
+int HgScanner::scan_impl(const void *d_text, uint64_t nbytes, int buffer_size, uint64_t line_base, bool block_mode, hipStream_t stream,
+                         HgScanOutput *out) {
   if (!out || (!d_text && nbytes) || buffer_size < 2) {
     err_ = "invalid arguments";
     return HG_ERR_ARG;
@@ -318,7 +360,7 @@ int HgScanner::scan(const void *d_text, uint64_t nbytes, int buffer_size, uint64
   uint32_t reruns = 0;
   for (;;) {
     bool overflow = false;
-    rc = run_once(static_cast<const uint8_t *>(d_text), nbytes, bs1, line_base, stream, out, &overflow);
+    rc = run_once(static_cast<const uint8_t *>(d_text), nbytes, bs1, line_base, block_mode, stream, out, &overflow);
     if (rc) return rc;
     if (!overflow) break;
     if (++reruns > 8) {

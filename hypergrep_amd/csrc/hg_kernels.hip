@@ -2,16 +2,17 @@
 // (hypergrep/lib/c/hyperscanner.c:198-226: gzgets -> strlen -> hs_scan -> hs_callback per line) with
 //
 //   hg_stream_kernel      one pass over the text in HBM: 16 B per lane coalesced loads, per-dword window
-//                         hash (v_dot4_u32_u8) probed in a 32 KiB LDS bitmap, exact newline counts per
-//                         16 KiB wave tile, candidates compacted through a per-wave LDS queue
-//                         (ballot + mbcnt), literal verify, wave-aggregated append to HBM
+//                         fingerprint (v_dot4_u32_u8) probed in an LDS cuckoo filter, exact newline counts
+//                         per 16 KiB wave tile, window hits ranked (wave prefix sums) and appended to HBM
+//                         with one atomic per wave
 //   hg_tile_*             3-launch scan of the tile newline summaries -> global piece numbers
-//   hg_confirm_kernel     one lane per verified candidate: locate the line piece, run the pattern automaton
+//   hg_confirm_kernel     one lane per window hit: literal verify, locate the line piece, run the pattern automaton
 //   hg_always_on_kernel   patterns without a long enough required literal: every line, one wave per tile
 //   hg_key/gather/keep    ordering + SINGLEMATCH / duplicate rules (sort itself: rocPRIM radix sort)
 //
 // Byte/integer work, HBM-bound: no MFMA anywhere.  Wave64 only.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "hg_core.h"
 #include "hg_engine.h"
@@ -21,14 +22,8 @@ namespace {
 
 constexpr int WG_WAVES = 8;
 constexpr int WG_THREADS = WG_WAVES * 64;
-constexpr int QCAP = 512;        // queue entries per wave (8 B each)
-constexpr int QDRAIN = QCAP - 256;  // one iteration can push at most 64 lanes x 4 dwords
 constexpr int ITERS = HG_TILE_BYTES / 1024;  // 1 KiB per wave-iteration
 
-__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
-__device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
-  return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
-}
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -43,156 +38,287 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lan
   return v;
 }
 
-struct Queue {
-  uint2 *q;
-  uint32_t n;
-};
-
-// Lane-parallel verify of queued window hits; verified ones are appended to the candidate buffer in HBM.
-__device__ __noinline__ void drain_queue(const HgStreamArgs &a, Queue &qu, uint64_t tile_base, uint32_t lane) {
-  const uint8_t *text = a.text;
-  for (uint32_t i = lane; i < qu.n; i += 64) {
-    uint2 e = qu.q[i];
-    uint64_t pos = tile_base + static_cast<uint64_t>(e.x & 0xFFFu) * 4u;
-    uint32_t rank = e.x >> 12;
-    hg_verify_window(a.db, text, a.nbytes, pos, e.y, [&](uint32_t pattern) {
-      uint32_t idx = atomicAdd(&a.counters[HG_CNT_CANDS], 1u);
-      if (idx < a.cand_cap) a.cands[idx] = HgCand{pos, pattern, rank};
-    });
-  }
-  qu.n = 0;
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
 // Stream pass.  One wave owns one 16 KiB tile at a time; tiles are dealt round-robin over all resident
 // waves so that at any moment the chip streams one contiguous window of the text.
-__global__ __launch_bounds__(WG_THREADS) void hg_stream_kernel(HgStreamArgs a) {
-  __shared__ uint32_t s_bitmap[HG_BITMAP_WORDS];
-  __shared__ uint2 s_queue[WG_WAVES][QCAP];
+//
+// Per 16 bytes of text a lane spends: 1 coalesced 16 B load, 4 x (4 ops: exact newline count) and
+// 4 x (fold, 3 x v_dot4_u32_u8, 2 LDS u16 reads, 2 compares) for the window filter.  Ranks and the append
+// to the candidate buffer run only in iterations where some lane's fingerprint matched (~1e-5 per dword
+// plus the real occurrences), so the steady state is pure streaming.
+namespace {
 
+// "not a newline" bits: bit 7 of each byte is CLEAR iff that byte is '\n' (exact, no carries between bytes)
+__device__ __forceinline__ uint32_t not_newline_bits(uint32_t w) {
+  uint32_t b = ((w & 0x7f7f7f7fu) ^ 0x0a0a0a0au) + 0x7f7f7f7fu;  // bit 7 set iff the low 7 bits differ from 0x0a
+  return b | w | 0x7f7f7f7fu;                                     // ... or the byte's own bit 7 is set
+}
+
+// Rare path of one iteration: newline rank of every matching dword, then one LDS atomic per wave reserves
+// slots in the workgroup's private segment of the candidate buffer (a single global counter would cap the whole
+// kernel at ~90 atomics/us: measured 4.2 ms per 4 GiB for 0.36 M appends).
+__device__ __noinline__ void append_matches(HgCand *__restrict__ seg, uint32_t seg_cap, uint32_t *lds_count, uint64_t chunk_pos, uint32_t lane,
+                                            uint4 cur, uint32_t tot, uint32_t hits) {
+  const uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
+  uint32_t cnt[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) cnt[k] = __popc(~not_newline_bits(words[k]));
+  const uint32_t c = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+  uint32_t rank = wave_sum(tot) + wave_inclusive_scan(c, lane) - c;  // newlines in [tile start, this lane's chunk)
+  const uint32_t mine = __popc(hits);
+  const uint32_t incl = wave_inclusive_scan(mine, lane);
+  const uint32_t total = __shfl(incl, 63, 64);
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(lds_count, total);
+  uint32_t slot = __shfl(base, 0, 64) + incl - mine;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if ((hits >> k) & 1u) {
+      if (slot < seg_cap) seg[slot] = HgCand{chunk_pos + 4u * k, words[k], rank};
+      slot++;
+    }
+    rank += cnt[k];
+  }
+}
+
+template <int LOG2>
+struct Probe {
+  static constexpr uint32_t BYTE_MASK = ((1u << LOG2) - 1u) << 2;
+  // ANY_ONLY: non-zero iff any of the four windows matched (hot path); else bit k set iff window k matched
+  template <bool ANY_ONLY>
+  __device__ __forceinline__ static uint32_t probe4(const uint32_t *filter, uint32_t fold, uint32_t wa, uint32_t wb, uint4 v) {
+    const uint32_t f0 = v.x | fold, f1 = v.y | fold, f2 = v.z | fold, f3 = v.w | fold;
+    // the three hashes of the four windows first (independent v_dot4), then the eight LDS reads
+    const uint32_t a0 = hg_dot4(f0, wa), a1 = hg_dot4(f1, wa);
+    const uint32_t a2 = hg_dot4(f2, wa), a3 = hg_dot4(f3, wa);
+    const uint32_t b0 = hg_dot4(f0, wb), b1 = hg_dot4(f1, wb);
+    const uint32_t b2 = hg_dot4(f2, wb), b3 = hg_dot4(f3, wb);
+    const uint32_t c0 = hg_dot4(f0, HG_HASH_WEIGHTS), c1 = hg_dot4(f1, HG_HASH_WEIGHTS);
+    const uint32_t c2 = hg_dot4(f2, HG_HASH_WEIGHTS), c3 = hg_dot4(f3, HG_HASH_WEIGHTS);
+    const uint8_t *base = reinterpret_cast<const uint8_t *>(filter);
+    auto at = [&](uint32_t h) { return *reinterpret_cast<const uint32_t *>(base + (h & BYTE_MASK)); };
+    const uint32_t ta0 = at(a0), tb0 = at(b0), ta1 = at(a1), tb1 = at(b1), ta2 = at(a2), tb2 = at(b2), ta3 = at(a3), tb3 = at(b3);
+    if (ANY_ONLY) return (ta0 == c0 || tb0 == c0 || ta1 == c1 || tb1 == c1 || ta2 == c2 || tb2 == c2 || ta3 == c3 || tb3 == c3) ? 1u : 0u;
+    uint32_t hits = (ta0 == c0 || tb0 == c0) ? 1u : 0u;
+    hits |= (ta1 == c1 || tb1 == c1) ? 2u : 0u;
+    hits |= (ta2 == c2 || tb2 == c2) ? 4u : 0u;
+    hits |= (ta3 == c3 || tb3 == c3) ? 8u : 0u;
+    return hits;
+  }
+};
+
+// Second level, entered when some lane's fingerprint matched: the dwords before and after the window must
+// agree (byte-masked) with what the slot's literals have there.  Returns bit k set iff window k survives.
+template <int LOG2>
+__device__ __forceinline__ uint32_t level2_filter(const uint32_t *filter, const HgFilterExt *ext, uint32_t fold, uint32_t wa, uint32_t wb, uint4 v, uint32_t lane) {
+  constexpr uint32_t BYTE_MASK = ((1u << LOG2) - 1u) << 2;
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  // neighbours across the lane edge come from the adjacent lanes; the first / last lane of the wave has none
+  const uint32_t left = __shfl_up(v.w, 1, 64), right = __shfl_down(v.x, 1, 64);
+  const uint8_t *base = reinterpret_cast<const uint8_t *>(filter);
+  uint32_t out = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t f = w[k] | fold;
+    const uint32_t sa = hg_dot4(f, wa) & BYTE_MASK, sb = hg_dot4(f, wb) & BYTE_MASK;
+    const uint32_t fp = hg_dot4(f, HG_HASH_WEIGHTS);
+    const bool ha = *reinterpret_cast<const uint32_t *>(base + sa) == fp, hb = *reinterpret_cast<const uint32_t *>(base + sb) == fp;
+    if (ha || hb) {
+      const uint32_t prev = (k == 0 ? left : w[k - 1]) | fold, next = (k == 3 ? right : w[k + 1]) | fold;
+      const bool no_prev = k == 0 && lane == 0, no_next = k == 3 && lane == 63;
+      bool ok = false;
+      if (ha) {
+        HgFilterExt e = ext[sa >> 2];
+        if (no_prev) e.pm = 0, e.pv = 0;
+        if (no_next) e.nm = 0, e.nv = 0;
+        ok = hg_ext_pass(e, prev, next);
+      }
+      if (hb && !ok) {
+        HgFilterExt e = ext[sb >> 2];
+        if (no_prev) e.pm = 0, e.pv = 0;
+        if (no_next) e.nm = 0, e.nv = 0;
+        ok = hg_ext_pass(e, prev, next);
+      }
+      if (ok) out |= 1u << k;
+    }
+  }
+  return out;
+}
+
+// One tile.  FULL: the tile lies entirely inside the text (no bounds checks on the hot path).
+template <int LOG2, bool FULL>
+__device__ __forceinline__ void stream_tile(const uint4 *__restrict__ text16, uint64_t nbytes, uint64_t tile, const uint32_t *filter,
+                                            const HgFilterExt *ext, uint32_t fold, uint32_t wa, uint32_t wb, HgTileSum *__restrict__ sums, HgCand *__restrict__ seg, uint32_t seg_cap,
+                                            uint32_t *lds_count, uint32_t lane) {
+  const uint64_t chunk0 = tile * (HG_TILE_BYTES / 16) + lane;
+  const uint64_t nchunks = (nbytes + 15) >> 4;  // 16-byte chunks holding at least one valid byte
+
+  auto load_chunk = [&](int it) -> uint4 {
+    const uint64_t g = chunk0 + static_cast<uint64_t>(it) * 64u;
+    if (FULL) return text16[g];
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (g < nchunks) {
+      v = text16[g];
+      const uint64_t byte0 = g << 4;
+      if (byte0 + 16 > nbytes) {  // zero the bytes past the end of the text
+        const uint32_t valid = static_cast<uint32_t>(nbytes - byte0);
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint32_t lo = k * 4u;
+          if (valid <= lo) w[k] = 0;
+          else if (valid < lo + 4) w[k] &= (1u << ((valid - lo) * 8)) - 1u;
+        }
+        v = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    }
+    return v;
+  };
+
+  uint32_t tot = 0;                            // newlines this lane saw in earlier iterations of the tile
+  uint32_t first_it = HG_NONE32, last_it = 0;  // wave-uniform: iterations holding the first / last newline
+  uint32_t first_lane = 0, last_lane = 0;
+
+  auto body = [&](int it, uint4 cur) {
+    // exact newline count of this lane's 16 bytes: 128 - popcount of the "not a newline" bits
+    uint32_t notnl = __popc(not_newline_bits(cur.x));
+    notnl += __popc(not_newline_bits(cur.y));
+    notnl += __popc(not_newline_bits(cur.z));
+    notnl += __popc(not_newline_bits(cur.w));
+    const uint32_t c = 128u - notnl;
+
+    const bool any = Probe<LOG2>::template probe4<true>(filter, fold, wa, wb, cur) != 0;
+
+    const uint64_t nlm = __ballot(c != 0);
+    if (nlm) {
+      if (first_it == HG_NONE32) {
+        first_it = it;
+        first_lane = __builtin_ctzll(nlm);
+      }
+      last_it = it;
+      last_lane = 63u - __builtin_clzll(nlm);
+    }
+    if (__ballot(any)) {
+      const uint32_t hits = level2_filter<LOG2>(filter, ext, fold, wa, wb, cur, lane);
+      if (__ballot(hits != 0))
+        append_matches(seg, seg_cap, lds_count, (chunk0 + static_cast<uint64_t>(it) * 64u) << 4, lane, cur, tot, hits);
+    }
+    tot += c;
+  };
+
+  constexpr int DEPTH = 3;  // 16-byte loads in flight per lane
+  if constexpr (FULL) {
+    uint4 buf[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) buf[d] = load_chunk(d);
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+      const uint4 cur = buf[it % DEPTH];
+      if (it + DEPTH < ITERS) buf[it % DEPTH] = load_chunk(it + DEPTH);
+      body(it, cur);
+    }
+  } else {
+#pragma unroll 1
+    for (int it = 0; it < ITERS; it++) body(it, load_chunk(it));
+  }
+
+  // tile summary: exact offsets of the first / last newline (re-read two 16-byte chunks, L2-resident)
+  const uint32_t nl_count = wave_sum(tot);
+  uint32_t first_nl = HG_NONE32, last_nl = HG_NONE32;
+  if (nl_count) {
+    auto chunk_masks = [&](uint32_t it_, uint32_t lane_) -> uint32_t {  // bit b set: byte b of the chunk is '\n'
+      const uint64_t g = tile * (HG_TILE_BYTES / 16) + it_ * 64u + lane_;
+      const uint4 v = text16[g];
+      const uint64_t byte0 = g << 4;
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+      uint32_t bitsm = 0;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const uint32_t m = hg_newline_mask(w[k]);
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+          if ((m >> (8 * b + 7)) & 1u) bitsm |= 1u << (k * 4 + b);
+      }
+      if (!FULL && byte0 + 16 > nbytes) bitsm &= (1u << static_cast<uint32_t>(nbytes - byte0)) - 1u;
+      return bitsm;
+    };
+    const uint32_t fm = chunk_masks(first_it, first_lane), lm = chunk_masks(last_it, last_lane);
+    first_nl = first_it * 1024u + first_lane * 16u + (__ffs(fm) - 1);
+    last_nl = last_it * 1024u + last_lane * 16u + (31 - __clz(lm));
+  }
+  if (lane == 0) sums[tile] = HgTileSum{nl_count, first_nl, last_nl, nl_count ? nl_count - 1 : 0};
+}
+
+}  // namespace
+
+template <int LOG2>
+__global__ __launch_bounds__(WG_THREADS, 8) void hg_stream_kernel(const uint4 *__restrict__ text16, uint64_t nbytes, uint64_t ntiles,
+                                                                  const uint4 *__restrict__ filter16, const uint4 *__restrict__ ext16,
+                                                                  uint32_t fold, uint32_t wa, uint32_t wb, HgTileSum *__restrict__ sums,
+                                                                  HgCand *__restrict__ cands, uint32_t seg_cap,
+                                                                  uint32_t *__restrict__ seg_count, uint32_t *__restrict__ counters) {
+  // LDS: window hash slots (4 B each) and, while they fit, the slots' neighbour conditions (16 B each)
+  constexpr bool EXT_IN_LDS = LOG2 <= 12;
+  __shared__ __attribute__((aligned(16))) uint32_t s_filter[1u << LOG2];
+  __shared__ __attribute__((aligned(16))) HgFilterExt s_ext[EXT_IN_LDS ? (1u << LOG2) : 1];
+  __shared__ uint32_t s_cand_n;
   {
-    const uint4 *src = reinterpret_cast<const uint4 *>(a.bitmap);
-    uint4 *dst = reinterpret_cast<uint4 *>(s_bitmap);
-    for (uint32_t i = threadIdx.x; i < HG_BITMAP_WORDS / 4; i += WG_THREADS) dst[i] = src[i];
+    uint4 *dst = reinterpret_cast<uint4 *>(s_filter);
+    for (uint32_t i = threadIdx.x; i < (4u << LOG2) / 16; i += WG_THREADS) dst[i] = filter16[i];
+    if (EXT_IN_LDS) {
+      uint4 *edst = reinterpret_cast<uint4 *>(s_ext);
+      for (uint32_t i = threadIdx.x; i < (1u << LOG2); i += WG_THREADS) edst[i] = ext16[i];
+    }
+    if (threadIdx.x == 0) s_cand_n = 0;
   }
   __syncthreads();
-
+  const HgFilterExt *ext = EXT_IN_LDS ? s_ext : reinterpret_cast<const HgFilterExt *>(ext16);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  Queue qu{s_queue[wave], 0};
-  const uint32_t fold = a.db.fold_mask;
-  const uint64_t nchunks = (a.nbytes + 15) >> 4;  // 16-byte chunks holding at least one valid byte
-  const uint4 *text16 = reinterpret_cast<const uint4 *>(a.text);
   const uint64_t tile_stride = static_cast<uint64_t>(gridDim.x) * WG_WAVES;
-
-  for (uint64_t tile = static_cast<uint64_t>(blockIdx.x) * WG_WAVES + wave; tile < a.ntiles; tile += tile_stride) {
-    const uint64_t tile_base = tile << HG_TILE_SHIFT;
-    const uint64_t chunk0 = tile * (HG_TILE_BYTES / 16) + lane;
-    const bool full = tile_base + HG_TILE_BYTES <= a.nbytes;  // wave-uniform
-
-    auto load_chunk = [&](int it) -> uint4 {
-      uint64_t g = chunk0 + static_cast<uint64_t>(it) * 64u;
-      if (full) return text16[g];
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (g < nchunks) {
-        v = text16[g];
-        uint64_t byte0 = g << 4;
-        if (byte0 + 16 > a.nbytes) {  // zero the bytes past the end of the text
-          uint32_t valid = static_cast<uint32_t>(a.nbytes - byte0);
-          uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-          for (int k = 0; k < 4; k++) {
-            uint32_t lo = k * 4u;
-            if (valid <= lo) w[k] = 0;
-            else if (valid < lo + 4) w[k] &= (1u << ((valid - lo) * 8)) - 1u;
-          }
-          v = make_uint4(w[0], w[1], w[2], w[3]);
-        }
-      }
-      return v;
-    };
-
-    uint32_t tot = 0;                              // newlines this lane saw in earlier iterations of the tile
-    uint32_t first_it = HG_NONE32, last_it = 0;    // wave-uniform: iterations holding the first / last newline
-    uint32_t first_lane = 0, last_lane = 0;
-
-    uint4 cur = load_chunk(0);
-    uint4 nxt = load_chunk(1);
-#pragma unroll 2
-    for (int it = 0; it < ITERS; it++) {
-      uint4 nn = make_uint4(0, 0, 0, 0);
-      if (it + 2 < ITERS) nn = load_chunk(it + 2);
-
-      const uint32_t w0 = cur.x, w1 = cur.y, w2 = cur.z, w3 = cur.w;
-      const uint32_t m0 = hg_newline_mask(w0), m1 = hg_newline_mask(w1), m2 = hg_newline_mask(w2), m3 = hg_newline_mask(w3);
-      const uint32_t c0 = __popc(m0), c1 = c0 + __popc(m1), c2 = c1 + __popc(m2), c = c2 + __popc(m3);
-
-      const uint32_t h0 = hg_hash_window(w0 | fold), h1 = hg_hash_window(w1 | fold);
-      const uint32_t h2 = hg_hash_window(w2 | fold), h3 = hg_hash_window(w3 | fold);
-      const uint32_t b0 = (s_bitmap[h0 >> 5] >> (h0 & 31u)) & 1u, b1 = (s_bitmap[h1 >> 5] >> (h1 & 31u)) & 1u;
-      const uint32_t b2 = (s_bitmap[h2 >> 5] >> (h2 & 31u)) & 1u, b3 = (s_bitmap[h3 >> 5] >> (h3 & 31u)) & 1u;
-
-      const uint64_t nlm = __ballot(c != 0);
-      if (nlm) {
-        if (first_it == HG_NONE32) {
-          first_it = it;
-          first_lane = __builtin_ctzll(nlm);
-        }
-        last_it = it;
-        last_lane = 63u - __builtin_clzll(nlm);
-      }
-
-      if (__ballot((b0 | b1 | b2 | b3) != 0)) {
-        // rare path: rank = newlines in [tile start, this dword)
-        const uint32_t before = wave_sum(tot) + wave_inclusive_scan(c, lane) - c;
-        const uint32_t didx = static_cast<uint32_t>(it) * 256u + lane * 4u;
-        const uint32_t bits[4] = {b0, b1, b2, b3};
-        const uint32_t ranks[4] = {before, before + c0, before + c1, before + c2};
-        const uint32_t words[4] = {w0, w1, w2, w3};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const uint64_t mk = __ballot(bits[k] != 0);
-          if (mk) {
-            if (bits[k]) qu.q[qu.n + mbcnt64(mk)] = make_uint2((didx + k) | (ranks[k] << 12), words[k]);
-            qu.n += __popcll(mk);
-          }
-        }
-        if (qu.n >= QDRAIN) drain_queue(a, qu, tile_base, lane);
-      }
-      tot += c;
-      cur = nxt;
-      nxt = nn;
-    }
-    if (qu.n) drain_queue(a, qu, tile_base, lane);
-
-    // tile summary: exact offsets of the first / last newline (re-read two 16-byte chunks, L2-resident)
-    const uint32_t nl_count = wave_sum(tot);
-    uint32_t first_nl = HG_NONE32, last_nl = HG_NONE32;
-    if (nl_count) {
-      auto chunk_masks = [&](uint32_t it_, uint32_t lane_) -> uint32_t {  // bit b set: byte b of the chunk is '\n'
-        uint64_t g = tile * (HG_TILE_BYTES / 16) + it_ * 64u + lane_;
-        uint4 v = text16[g];
-        uint64_t byte0 = g << 4;
-        uint32_t w[4] = {v.x, v.y, v.z, v.w};
-        uint32_t bitsm = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          uint32_t m = hg_newline_mask(w[k]);
-#pragma unroll
-          for (int b = 0; b < 4; b++)
-            if ((m >> (8 * b + 7)) & 1u) bitsm |= 1u << (k * 4 + b);
-        }
-        if (byte0 + 16 > a.nbytes) bitsm &= (1u << static_cast<uint32_t>(a.nbytes - byte0)) - 1u;
-        return bitsm;
-      };
-      uint32_t fm = chunk_masks(first_it, first_lane), lm = chunk_masks(last_it, last_lane);
-      first_nl = first_it * 1024u + first_lane * 16u + (__ffs(fm) - 1);
-      last_nl = last_it * 1024u + last_lane * 16u + (31 - __clz(lm));
-    }
-    if (lane == 0) a.sums[tile] = HgTileSum{nl_count, first_nl, last_nl, nl_count ? nl_count - 1 : 0};
+  const uint64_t full_tiles = nbytes >> HG_TILE_SHIFT;
+  HgCand *seg = cands + static_cast<uint64_t>(blockIdx.x) * seg_cap;  // this workgroup's private output segment
+  for (uint64_t tile = static_cast<uint64_t>(blockIdx.x) * WG_WAVES + wave; tile < ntiles; tile += tile_stride) {
+    if (tile < full_tiles) stream_tile<LOG2, true>(text16, nbytes, tile, s_filter, ext, fold, wa, wb, sums, seg, seg_cap, &s_cand_n, lane);
+    else stream_tile<LOG2, false>(text16, nbytes, tile, s_filter, ext, fold, wa, wb, sums, seg, seg_cap, &s_cand_n, lane);
   }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t n = s_cand_n;
+    seg_count[blockIdx.x] = n < seg_cap ? n : seg_cap;
+    atomicAdd(&counters[HG_CNT_CANDS], n < seg_cap ? n : seg_cap);
+    if (n > seg_cap) atomicMax(&counters[HG_CNT_CAND_NEED], n);
+  }
+}
+
+// Host-side launcher: picks the instantiation for the database's filter size.
+void hg_launch_stream(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
+  const uint4 *t = reinterpret_cast<const uint4 *>(a.text);
+  const uint4 *f = reinterpret_cast<const uint4 *>(a.filter);
+  const uint4 *x = reinterpret_cast<const uint4 *>(a.ext);
+#define HG_CASE(L)                                                                                                              \
+  case L:                                                                                                                       \
+    hipLaunchKernelGGL((hg_stream_kernel<L>), dim3(grid), dim3(WG_THREADS), 0, stream, t, a.nbytes, a.ntiles, f, x, a.db.fold_mask, a.weights_a, a.weights_b, \
+                       a.sums, a.cands, a.cand_seg_cap, a.seg_count, a.counters);                                                                \
+    break;
+  switch (a.filter_log2) {
+    HG_CASE(11) HG_CASE(12) HG_CASE(13) HG_CASE(14) HG_CASE(15)
+    default: break;
+  }
+#undef HG_CASE
+}
+int hg_stream_blocks_per_cu(uint32_t filter_log2) {
+  int n = 0;
+#define HG_CASE(L) \
+  case L: (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (hg_stream_kernel<L>), WG_THREADS, 0); break;
+  switch (filter_log2) {
+    HG_CASE(11) HG_CASE(12) HG_CASE(13) HG_CASE(14) HG_CASE(15)
+    default: break;
+  }
+#undef HG_CASE
+  return n > 0 ? n : 1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -200,7 +326,6 @@ __global__ __launch_bounds__(WG_THREADS) void hg_stream_kernel(HgStreamArgs a) {
 namespace {
 constexpr int TS_THREADS = 256;
 constexpr int TS_PER_THREAD = 4;
-constexpr int TS_BLOCK_TILES = TS_THREADS * TS_PER_THREAD;
 
 __device__ HgTileElem identity_elem() {
   HgTileElem e;
@@ -289,15 +414,6 @@ __global__ __launch_bounds__(TS_THREADS) void hg_tile_apply_kernel(const HgTileS
 }
 
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void append_hit(const HgConfirmArgs &a, uint64_t line_no, uint32_t id, uint32_t to, uint64_t start,
-                                           uint32_t len, uint32_t pattern) {
-  uint32_t idx = atomicAdd(&a.counters[HG_CNT_HITS], 1u);
-  if (idx < a.hit_cap) {
-    a.hits[idx] = HgHit{line_no, id, to};
-    a.aux[idx] = HgHitAux{start, len, pattern};
-  }
-}
-
 // Small-buffer mode only (buffer_size - 1 < tile): lines inside a tile may split into several pieces, so the
 // per-tile count of inner pieces is recomputed by walking the tile (one thread per tile; slow path).
 __global__ __launch_bounds__(256) void hg_tile_inner_kernel(const uint8_t *text, HgTileSum *sums, uint64_t ntiles, uint64_t bs1) {
@@ -309,20 +425,69 @@ __global__ __launch_bounds__(256) void hg_tile_inner_kernel(const uint8_t *text,
   }
 }
 
-// One lane per verified candidate.
-__global__ __launch_bounds__(256) void hg_confirm_kernel(HgConfirmArgs a) {
-  uint32_t n = a.counters[HG_CNT_CANDS];
-  if (n > a.cand_cap) n = a.cand_cap;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    HgCand c = a.cands[i];
-    const uint32_t id = a.db.patterns[c.pattern].id;
-    hg_confirm(a.db, a.text, a.nbytes, a.sums, a.bases, a.bs1, c.pos, c.pattern, c.rank,
-               [&](uint64_t line_no, uint32_t to, uint64_t start, uint32_t len) { append_hit(a, line_no, id, to, start, len, c.pattern); });
+// Hits are first appended to a block-private segment (LDS counter), then each block reserves one contiguous
+// range of the compact output with a single global atomic and copies its segment there.
+struct HitSink {
+  HgHit *seg_hits;
+  HgHitAux *seg_aux;
+  uint32_t seg_cap;
+  uint32_t *lds_count;
+  __device__ __forceinline__ void push(uint64_t line_no, uint32_t id, uint32_t to, uint64_t start, uint32_t len, uint32_t pattern) const {
+    const uint32_t slot = atomicAdd(lds_count, 1u);
+    if (slot < seg_cap) {
+      seg_hits[slot] = HgHit{line_no, id, to};
+      seg_aux[slot] = HgHitAux{start, len, pattern};
+    }
   }
+};
+
+__device__ __forceinline__ void flush_hits(const HgConfirmArgs &a, uint32_t *lds_count, uint32_t *lds_base) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t n = *lds_count;
+    const uint32_t kept = n < a.hit_seg_cap ? n : a.hit_seg_cap;
+    *lds_base = atomicAdd(&a.counters[HG_CNT_HITS], kept);
+    if (n > a.hit_seg_cap) atomicMax(&a.counters[HG_CNT_HIT_NEED], n);
+    *lds_count = kept;
+  }
+  __syncthreads();
+  const uint32_t n = *lds_count, base = *lds_base;
+  const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    if (base + i < a.hit_cap) {
+      a.hits[base + i] = a.tmp_hits[seg0 + i];
+      a.aux[base + i] = a.tmp_aux[seg0 + i];
+    }
+  }
+}
+
+// One lane per window hit of the stream pass; block b consumes segment b of the candidate buffer.
+__global__ __launch_bounds__(256) void hg_confirm_kernel(HgConfirmArgs a) {
+  __shared__ uint32_t s_n, s_base;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
+  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n};
+  const HgCand *cseg = a.cands + static_cast<uint64_t>(blockIdx.x) * a.cand_seg_cap;
+  const uint32_t n = a.seg_count[blockIdx.x];
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const HgCand c = cseg[i];
+    hg_verify_window(a.db, a.text, a.nbytes, c.pos, c.word, [&](uint32_t pattern) {
+      const uint32_t id = a.db.patterns[pattern].id;
+      hg_confirm(a.db, a.text, a.nbytes, a.sums, a.bases, a.bs1, c.pos, pattern, c.rank,
+                 [&](uint64_t line_no, uint32_t to, uint64_t start, uint32_t len) { sink.push(line_no, id, to, start, len, pattern); });
+    });
+  }
+  flush_hits(a, &s_n, &s_base);
 }
 
 // Always-on tier: one wave per tile, each lane owns 256 bytes and handles the lines that START there.
 __global__ __launch_bounds__(256) void hg_always_on_kernel(HgConfirmArgs a) {
+  __shared__ uint32_t s_n, s_base;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
+  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n};
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
   for (uint64_t tile = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6; tile < a.ntiles; tile += waves) {
@@ -337,11 +502,40 @@ __global__ __launch_bounds__(256) void hg_always_on_kernel(HgConfirmArgs a) {
       if (starts)
         hg_scan_line_always_on(a.db, a.text, a.nbytes, a.sums, a.bases, a.bs1, s, rank,
                                [&](uint32_t pi, uint64_t line_no, uint32_t to, uint64_t start, uint32_t len) {
-                                 append_hit(a, line_no, a.db.patterns[pi].id, to, start, len, pi);
+                                 sink.push(line_no, a.db.patterns[pi].id, to, start, len, pi);
                                });
       rank += a.text[s] == '\n';
     }
   }
+  flush_hits(a, &s_n, &s_base);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Block mode (Face A, hs_scan): the whole buffer is ONE scan unit, newlines are ordinary bytes.
+// Pass 1 marks the patterns whose required literal really occurs somewhere in the block; pass 2 runs each marked
+// (or always-on) pattern's automaton over the whole block, one lane per pattern.
+__global__ __launch_bounds__(256) void hg_block_mark_kernel(HgConfirmArgs a, uint32_t *pattern_flags) {
+  const HgCand *cseg = a.cands + static_cast<uint64_t>(blockIdx.x) * a.cand_seg_cap;
+  const uint32_t n = a.seg_count[blockIdx.x];
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const HgCand c = cseg[i];
+    hg_verify_window(a.db, a.text, a.nbytes, c.pos, c.word, [&](uint32_t pattern) { pattern_flags[pattern] = 1; });
+  }
+}
+
+__global__ __launch_bounds__(256) void hg_block_scan_kernel(HgConfirmArgs a, const uint32_t *pattern_flags) {
+  __shared__ uint32_t s_n, s_base;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
+  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n};
+  for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < a.db.npatterns; p += gridDim.x * blockDim.x) {
+    const HgPattern &pat = a.db.patterns[p];
+    if (pat.tier == 0 && !pattern_flags[p]) continue;
+    hg_nfa_scan(a.db.pool, pat, a.text, a.nbytes,
+                [&](uint32_t to) { sink.push(0, pat.id, to, 0, static_cast<uint32_t>(a.nbytes), p); });
+  }
+  flush_hits(a, &s_n, &s_base);
 }
 
 // ------------------------------------------------------------------------------------------------

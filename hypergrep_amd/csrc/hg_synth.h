@@ -25,6 +25,9 @@ struct HgSynthSpec {
   const uint32_t *needle_off;
 };
 
+// Uniform pick in [0, n) from 32 random bits without any division (identical on host and device).
+HG_HD uint32_t hg_pick(uint32_t r32, uint32_t n) { return static_cast<uint32_t>((static_cast<uint64_t>(r32) * n) >> 32); }
+
 HG_HD uint64_t hg_splitmix(uint64_t &s) {
   uint64_t z = (s += 0x9E3779B97F4A7C15ull);
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -88,13 +91,13 @@ struct Out {
   HG_HD void str(const char *s) {
     while (*s) put(static_cast<uint8_t>(*s++));
   }
-  HG_HD void num(uint32_t v, int width) {  // zero padded decimal
-    uint32_t div = 1;
-    for (int i = 1; i < width; i++) div *= 10;
-    for (int i = 0; i < width; i++) {
-      put(static_cast<uint8_t>('0' + (v / div) % 10));
-      div /= 10;
-    }
+  HG_HD void num(uint32_t v, int width) {  // zero padded decimal, width <= 5; constant divisions only
+    const uint32_t d0 = v % 10u, d1 = (v / 10u) % 10u, d2 = (v / 100u) % 10u, d3 = (v / 1000u) % 10u, d4 = (v / 10000u) % 10u;
+    if (width >= 5) put(static_cast<uint8_t>('0' + d4));
+    if (width >= 4) put(static_cast<uint8_t>('0' + d3));
+    if (width >= 3) put(static_cast<uint8_t>('0' + d2));
+    if (width >= 2) put(static_cast<uint8_t>('0' + d1));
+    put(static_cast<uint8_t>('0' + d0));
   }
 };
 }  // namespace hg_synth_detail
@@ -109,27 +112,29 @@ HG_HD uint32_t hg_synth_block(const HgSynthSpec &sp, uint64_t b, uint8_t *out, u
   // a line never exceeds 24+9+7+6 + 12 tokens x 20 + needle 97 < 400 bytes
   while (o.n + 400 < HG_SYNTH_BLOCK) {
     uint64_t r = hg_splitmix(s);
+    const uint32_t ra = static_cast<uint32_t>(r), rb = static_cast<uint32_t>(r >> 32);
     o.str("2026-10-");
-    o.num(1 + static_cast<uint32_t>(r % 28), 2);
+    o.num(1 + hg_pick(ra, 28), 2);
     o.put('T');
-    o.num(static_cast<uint32_t>((r >> 8) % 24), 2);
+    o.num(hg_pick(ra * 0x9E3779B1u, 24), 2);
     o.put(':');
-    o.num(static_cast<uint32_t>((r >> 16) % 60), 2);
+    o.num(hg_pick(ra * 0x85EBCA6Bu, 60), 2);
     o.put(':');
-    o.num(static_cast<uint32_t>((r >> 24) % 60), 2);
+    o.num(hg_pick(ra * 0xC2B2AE35u, 60), 2);
     o.put('.');
-    o.num(static_cast<uint32_t>((r >> 32) % 1000), 3);
+    o.num(hg_pick(rb, 1000), 3);
     o.str("Z host-");
-    o.num(static_cast<uint32_t>((r >> 42) % 1000), 3);
+    o.num(hg_pick(rb * 0x9E3779B1u, 1000), 3);
     o.str(" svc-");
-    o.num(static_cast<uint32_t>((r >> 52) % 100), 2);
+    o.num(hg_pick(rb * 0x85EBCA6Bu, 100), 2);
     o.put(' ');
     uint64_t r2 = hg_splitmix(s);
-    o.str(level(static_cast<uint32_t>(r2)));
-    uint32_t ntok = 1 + static_cast<uint32_t>((r2 >> 4) % 12);
-    bool has_needle = sp.n_needles && (static_cast<uint32_t>((r2 >> 16) % 1000000u) < sp.hit_per_million);
-    uint32_t needle_at = static_cast<uint32_t>((r2 >> 40) % ntok);
-    uint32_t needle_ix = sp.n_needles ? static_cast<uint32_t>((r2 >> 48) % sp.n_needles) : 0;
+    const uint32_t rc = static_cast<uint32_t>(r2), rd = static_cast<uint32_t>(r2 >> 32);
+    o.str(level(rc >> 30));
+    uint32_t ntok = 1 + hg_pick(rc * 0x9E3779B1u, 12);
+    bool has_needle = sp.n_needles && (hg_pick(rd, 1000000u) < sp.hit_per_million);
+    uint32_t needle_at = hg_pick(rd * 0x9E3779B1u, ntok);
+    uint32_t needle_ix = sp.n_needles ? hg_pick(rd * 0x85EBCA6Bu, sp.n_needles) : 0;
     for (uint32_t t = 0; t < ntok; t++) {
       o.put(' ');
       if (has_needle && t == needle_at) {
@@ -137,12 +142,13 @@ HG_HD uint32_t hg_synth_block(const HgSynthSpec &sp, uint64_t b, uint8_t *out, u
         continue;
       }
       uint64_t r3 = hg_splitmix(s);
-      const char *w = word(static_cast<uint32_t>(r3));
+      const uint32_t re = static_cast<uint32_t>(r3), rf = static_cast<uint32_t>(r3 >> 32);
+      const char *w = word(re >> 27);
       o.str(w);
       // words ending in '=' take a numeric value
       const char *e = w;
       while (*e) e++;
-      if (e[-1] == '=') o.num(static_cast<uint32_t>((r3 >> 8) % 100000), 1 + static_cast<int>((r3 >> 40) % 5));
+      if (e[-1] == '=') o.num(hg_pick(rf, 100000), 1 + static_cast<int>(hg_pick(re * 0x9E3779B1u, 5)));
     }
     o.put('\n');
     needle_lines += has_needle ? 1u : 0u;

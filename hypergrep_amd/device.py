@@ -60,6 +60,7 @@ def lib() -> ctypes.CDLL:
         l.hg_scan_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p,
                                      ctypes.POINTER(HgScanResult)]
         l.hg_copy_hits.argtypes = [ctypes.c_void_p, ctypes.POINTER(HgHit), ctypes.POINTER(HgHitAux), ctypes.c_uint64]
+        l.hg_copy_hits_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
         l.hg_synth_device.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(HgSynthSpec), ctypes.c_int, ctypes.c_void_p]
         l.hg_synth_host.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.POINTER(HgSynthSpec)]
         _configured = True
@@ -143,6 +144,14 @@ class Scanner:
         if rc != 0:
             raise DeviceError(f"hg_copy_hits failed ({rc})")
         return [(hits[i].line_number, hits[i].id, hits[i].to, aux[i].start, aux[i].len) for i in range(n)]
+
+    def copy_hits_to(self, d_dst: int, limit: int, stream: int = 0) -> int:
+        """Async device-to-device copy of the last scan's hit records (16 B each); returns the number copied."""
+        n = min(limit, self._last.n_hits)
+        rc = lib().hg_copy_hits_device(self._h, ctypes.c_void_p(d_dst), n, ctypes.c_void_p(stream))
+        if rc != 0:
+            raise DeviceError(f"hg_copy_hits_device failed ({rc})")
+        return n
 
     def __del__(self):
         if getattr(self, "_h", None):

@@ -177,6 +177,10 @@ int hg_scan_device(hg_scanner_t *scanner, const void *d_text, uint64_t nbytes, i
 /* Copy the last scan's first `max` hits (and aux records, if aux != NULL) to host memory. */
 int hg_copy_hits(hg_scanner_t *scanner, hg_hit_t *hits, hg_hit_aux_t *aux, uint64_t max);
 
+/* Copy the last scan's first `max` hit records (16 B each) into another DEVICE buffer, asynchronously on
+ * `stream` (e.g. a tensor that is then sent over RCCL). */
+int hg_copy_hits_device(hg_scanner_t *scanner, void *d_dst, uint64_t max, void *stream);
+
 /* Deterministic synthetic log used by bench.py and the parity tests: writes nbytes at d_text (device)
  * or text (host) from the same counter-based generator; see hypergrep_amd/csrc/hg_synth.h. */
 typedef struct hg_synth_spec {

@@ -81,13 +81,13 @@ class Db:
     def scan(self, data: bytes, buffer_size: int = 262140):
         """Returns (hits, stats); hits = list of (line_no, id, to, start, len)."""
         out = ctypes.POINTER(SimHit)()
-        stats = (ctypes.c_uint64 * 4)()
+        stats = (ctypes.c_uint64 * 5)()
         n = lib().hgsim_scan(self.h, data, len(data), buffer_size, ctypes.byref(out), stats)
         if n < 0:
             raise RuntimeError(f"hgsim_scan rc {n}")
         hits = [(out[i].line_no, out[i].id, out[i].to, out[i].start, out[i].len) for i in range(n)]
         lib().hgsim_free_hits(out)
-        return hits, dict(zip(("bitmap_hits", "candidates", "raw_hits", "pieces"), stats))
+        return hits, dict(zip(("bitmap_hits", "candidates", "raw_hits", "pieces", "level2_hits"), stats))
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -1,6 +1,6 @@
 // TEST-ONLY host harness (never shipped, never loaded by the product): compiles the product's pattern
 // compiler and hg_core.h for x86 and replays the GPU pipeline's stages in scalar form —
-//   stream pass (newline summaries + window bitmap + literal verify)  ~ hg_stream_kernel
+//   stream pass (newline summaries + window fingerprint filter + literal verify)  ~ hg_stream_kernel
 //   tile scan                                                          ~ hg_tile_scan_*
 //   confirm / always-on                                                ~ hg_confirm_kernel / hg_always_on_kernel
 //   order + dedupe                                                     ~ hg_finalize
@@ -74,7 +74,7 @@ static HgDbView view_of(HgDb *db) {
 }
 
 // Whole pipeline on a memory buffer.  Returns number of hits (after dedupe); *out is malloc'ed.
-// stats[0] = window bitmap hits, stats[1] = verified candidates, stats[2] = raw hits before dedupe, stats[3] = pieces
+// stats[4] = hits surviving the neighbour-dword check; stats[0] = window fingerprint filter hits, stats[1] = verified candidates, stats[2] = raw hits before dedupe, stats[3] = pieces
 long hgsim_scan(void *h, const uint8_t *data, uint64_t nbytes, int buffer_size, SimHit **out, uint64_t *stats) {
   HgDb *db = static_cast<HgDb *>(h);
   HgDbView v = view_of(db);
@@ -84,7 +84,7 @@ long hgsim_scan(void *h, const uint8_t *data, uint64_t nbytes, int buffer_size, 
   std::vector<HgTileSum> sums(ntiles ? ntiles : 1);
   std::vector<HgTileBase> bases(ntiles + 1);
   std::vector<HgCand> cands;
-  uint64_t bitmap_hits = 0;
+  uint64_t bitmap_hits = 0, level2_hits = 0;
   // ---- stream pass
   for (uint64_t t = 0; t < ntiles; t++) {
     uint64_t base = t * HG_TILE_BYTES;
@@ -105,10 +105,33 @@ long hgsim_scan(void *h, const uint8_t *data, uint64_t nbytes, int buffer_size, 
           }
         s.nl_count += hg_popc(m);
       }
-      uint32_t hsh = hg_hash_window(w | v.fold_mask);
-      if (db->bitmap[hsh >> 5] >> (hsh & 31) & 1) {
+      const uint32_t folded = w | v.fold_mask, byte_mask = ((1u << db->filter_log2) - 1u) << 2;
+      const uint32_t fp = hg_hash_window(folded);
+      const uint32_t sla = hg_slot(folded, db->weights_a, byte_mask) >> 2, slb = hg_slot(folded, db->weights_b, byte_mask) >> 2;
+      const bool ha = db->filter[sla] == fp, hb = db->filter[slb] == fp;
+      if (ha || hb) {
         bitmap_hits++;
-        hg_verify_window(v, data, nbytes, pos, w, [&](uint32_t pattern) { cands.push_back(HgCand{pos, pattern, rank_here}); });
+        // second level: neighbour dwords (bytes outside the text read as zero, like the kernel's masked tail)
+        auto dword_at = [&](int64_t p) -> uint32_t {
+          uint32_t x = 0;
+          for (int b = 0; b < 4; b++)
+            if (p + b >= 0 && static_cast<uint64_t>(p + b) < nbytes) x |= static_cast<uint32_t>(data[p + b]) << (8 * b);
+          return x;
+        };
+        const uint32_t pf = dword_at(static_cast<int64_t>(pos) - 4) | v.fold_mask, nf = dword_at(static_cast<int64_t>(pos) + 4) | v.fold_mask;
+        // the kernel cannot see across its 16 KiB tile edge or the first/last lane of a 1 KiB segment: treat as pass there
+        const bool edge_prev = (pos % 1024) == 0, edge_next = (pos % 1024) == 1020;
+        auto pass = [&](uint32_t sl) {
+          HgFilterExt e = db->ext[sl];
+          if (edge_prev) e.pm = 0;
+          if (edge_next) e.nm = 0;
+          e.pv &= e.pm;
+          e.nv &= e.nm;
+          return hg_ext_pass(e, pf, nf);
+        };
+        if (!((ha && pass(sla)) || (hb && pass(slb)))) continue;
+        level2_hits++;
+        cands.push_back(HgCand{pos, w, rank_here});
       }
     }
     s.inner = s.nl_count ? s.nl_count - 1 : 0;
@@ -127,12 +150,16 @@ long hgsim_scan(void *h, const uint8_t *data, uint64_t nbytes, int buffer_size, 
   // ---- confirm
   std::vector<HgHit> hits;
   std::vector<HgHitAux> aux;
+  uint64_t verified = 0;
   for (auto &c : cands) {
-    hg_confirm(v, data, nbytes, sums.data(), bases.data(), bs1, c.pos, c.pattern, c.rank,
-               [&](uint64_t line_no, uint32_t to, uint64_t a, uint32_t len) {
-                 hits.push_back(HgHit{line_no, db->patterns[c.pattern].id, to});
-                 aux.push_back(HgHitAux{a, len, c.pattern});
-               });
+    hg_verify_window(v, data, nbytes, c.pos, c.word, [&](uint32_t pattern) {
+      verified++;
+      hg_confirm(v, data, nbytes, sums.data(), bases.data(), bs1, c.pos, pattern, c.rank,
+                 [&](uint64_t line_no, uint32_t to, uint64_t a, uint32_t len) {
+                   hits.push_back(HgHit{line_no, db->patterns[pattern].id, to});
+                   aux.push_back(HgHitAux{a, len, pattern});
+                 });
+    });
   }
   // ---- always-on tier: every line start
   if (v.nslow) {
@@ -171,7 +198,7 @@ long hgsim_scan(void *h, const uint8_t *data, uint64_t nbytes, int buffer_size, 
   SimHit *res = static_cast<SimHit *>(malloc(sizeof(SimHit) * (kept.size() ? kept.size() : 1)));
   std::memcpy(res, kept.data(), sizeof(SimHit) * kept.size());
   *out = res;
-  if (stats) { stats[0] = bitmap_hits; stats[1] = cands.size(); stats[2] = raw; stats[3] = pieces; }
+  if (stats) { stats[0] = bitmap_hits; stats[1] = verified; stats[2] = raw; stats[3] = pieces; stats[4] = level2_hits; }
   return static_cast<long>(kept.size());
 }
 void hgsim_free_hits(SimHit *p) { free(p); }

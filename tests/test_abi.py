@@ -1,0 +1,102 @@
+"""CPU tests of the C-ABI boundary: the shared library loads without a GPU (every symbol resolved) and exports
+exactly the entry points include/hypergrep_amd.h declares; compile-only entry points work without a GPU and the
+scan entry points fail loudly instead of falling back to a CPU path."""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(REPO, "include", "hypergrep_amd.h")
+LIB = os.path.join(REPO, "hypergrep_amd", "lib", "libhyperscanner.so")
+
+
+def declared_functions() -> list[str]:
+    text = open(HEADER, encoding="utf-8").read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"^\s*(?:const\s+)?(?:int|void|char|uint64_t)\s*\*?\s*(\w+)\s*\(", text, flags=re.M)
+    return sorted(set(n for n in names if n.startswith(("hg_", "hs_")) or n in ("hyperscan", "check_patterns")))
+
+
+def test_header_declares_the_three_faces():
+    names = declared_functions()
+    for must in ("hyperscan", "check_patterns", "hs_compile_multi", "hs_free_compile_error", "hs_alloc_scratch", "hs_scan",
+                 "hs_free_scratch", "hs_free_database", "hg_db_compile", "hg_scan_device", "hg_copy_hits"):
+        assert must in names
+
+
+def test_library_loads_with_all_symbols_resolved():
+    # RTLD_NOW: an unresolved kernel stub or helper would fail here, on a box without any GPU
+    lib = ctypes.CDLL(LIB, mode=os.RTLD_NOW)
+    for name in declared_functions():
+        assert hasattr(lib, name), f"{name} is declared in include/hypergrep_amd.h but not exported"
+
+
+def test_only_the_c_abi_is_exported():
+    out = subprocess.check_output(["nm", "-D", "--defined-only", LIB], text=True)
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    extra = {s for s in exported if not (s in declared_functions() or s in ("_init", "_fini"))}
+    assert not extra, f"unexpected exported symbols: {sorted(extra)[:10]}"
+
+
+def test_compile_only_entry_points_need_no_gpu():
+    import hypergrep_amd
+
+    assert hypergrep_amd.check_compatibility(["foobar", "user=[a-z0-9_]{4,12} status=5[0-9]{2}"]) == 0
+    assert hypergrep_amd.check_compatibility(["(?<!foo)bar"]) == 4
+    with pytest.raises(ValueError):
+        hypergrep_amd.prepare_patterns([""])
+    with pytest.raises(ValueError):
+        hypergrep_amd.prepare_patterns(["a"], flags=[1, 2])
+    with pytest.raises(ValueError):
+        hypergrep_amd.prepare_patterns(["a"], ids=[1, 2])
+    pa, fa, ia = hypergrep_amd.prepare_patterns(["a", "b"])
+    assert list(fa) == [14, 14] and list(ia) == [0, 0]
+
+
+def test_python_api_error_paths_match_the_reference(tmp_path):
+    import hypergrep_amd
+
+    with pytest.raises(FileNotFoundError):
+        hypergrep_amd.grep(str(tmp_path / "missing"), ["x"])
+    assert hypergrep_amd.grep(str(tmp_path / "missing"), ["x"], no_messages=True) == ([], 101)
+    with pytest.raises(ValueError):
+        hypergrep_amd.grep(str(tmp_path), ["x"])
+    assert hypergrep_amd.grep(str(tmp_path), ["x"], no_messages=True) == ([], 101)
+    assert hypergrep_amd.RC_INVALID_FILE == 101 and hypergrep_amd.HS_FLAG_SINGLEMATCH == 8
+    assert ctypes.sizeof(hypergrep_amd.Result) == 24
+    assert hypergrep_amd.Result.line_number.offset == 8 and hypergrep_amd.Result.line.offset == 16
+
+
+def test_no_cpu_fallback_without_gpu(tmp_path):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("this box has a GPU")
+    import hypergrep_amd
+    from hypergrep_amd import device
+
+    path = tmp_path / "f.txt"
+    path.write_text("needle_in_haystack\n")
+    called = []
+    assert hypergrep_amd.scan(str(path), ["needle_in_haystack"], lambda m, c: called.append(c)) == 3  # HYPERSCANNER_SCRATCH
+    assert not called
+    with pytest.raises(device.DeviceError):
+        device.Scanner(device.Database(["needle_in_haystack"]))
+
+
+def test_synthetic_generator_is_deterministic_on_host():
+    from hypergrep_amd import benchspec, device
+
+    patterns, needles, hpm = benchspec.c3_spec()
+    a = device.synth_host(100000, 5, needles, hpm)
+    b = device.synth_host(100000, 5, needles, hpm)
+    assert a == b and a.count(b"\n") > 500
+    # a shard starting at block 3 equals the corresponding slice of the whole
+    whole = device.synth_host(5 * device.SYNTH_BLOCK, 5, needles, hpm)
+    part = device.synth_host(2 * device.SYNTH_BLOCK, 5, needles, hpm, first_block=3)
+    assert whole[3 * device.SYNTH_BLOCK:] == part

@@ -134,8 +134,8 @@ def test_grep_counts_on_greptest_files(torch_cuda):
     assert hypergrep_amd.grep(f1, ["foo"], max_match_count=3) == ([(2, "foo\n"), (3, "foobar\n"), (4, "[foo]\n")], 0)
     assert hypergrep_amd.grep(f1, ["fOoBaR"]) == ([], 0)
     assert hypergrep_amd.grep(f1, ["fOoBaR"], ignore_case=True) == ([(3, "foobar\n")], 0)
-    assert hypergrep_amd.grep(f1, ["barfoo\\+"]) == ([(13, "barfoo+\n")], 0)
-    assert hypergrep_amd.grep(f1, ["barfoo+"]) == ([(12, "barfoo\n"), (13, "barfoo+\n")], 0)
+    assert hypergrep_amd.grep(f1, ["barfoo\\+"]) == ([(12, "barfoo+\n")], 0)
+    assert hypergrep_amd.grep(f1, ["barfoo+"]) == ([(11, "barfoo\n"), (12, "barfoo+\n")], 0)
     assert hypergrep_amd.grep(f1, ["foobar", "fo{2}bar", "fo+bar"]) == ([(3, "foobar\n")], 0)
     assert hypergrep_amd.grep(f1, ["foobar", "extra foo bar"]) == ([(3, "foobar\n"), (16, "extra foo bar\n")], 0)
     got = hypergrep_amd.grep(f1, ["grep file to test|sync with"], only_matching=True)
@@ -297,3 +297,80 @@ def test_large_file_chunked_face_b(torch_cuda, tmp_path, monkeypatch):
     assert rc == 0
     orc, want, _ = oracle_py.scan_file(str(path), patterns, ids=ids, buffer_count=64)
     assert orc == 0 and rows == want and len(rows) > 500
+
+
+# ------------------------------------------------------------------ Face A: the six libhs symbols, block mode
+class _HsErr(__import__("ctypes").Structure):
+    _fields_ = [("message", __import__("ctypes").c_char_p), ("expression", __import__("ctypes").c_int)]
+
+
+def _hs_events(lib, patterns, flags, ids, blocks):
+    """Compile + scan each block through the libhs face of `lib`; returns [[(id, to), ...] per block]."""
+    import ctypes
+
+    handler_t = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_uint, ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_uint, ctypes.c_void_p)
+    n = len(patterns)
+    pa = (ctypes.c_char_p * n)(*[p.encode() for p in patterns])
+    fa = (ctypes.c_uint * n)(*flags)
+    ia = (ctypes.c_uint * n)(*ids)
+    db, err, scratch = ctypes.c_void_p(), ctypes.POINTER(_HsErr)(), ctypes.c_void_p()
+    lib.hs_compile_multi.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint), ctypes.c_uint,
+                                     ctypes.c_uint, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.POINTER(_HsErr))]
+    lib.hs_alloc_scratch.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
+    lib.hs_scan.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint, ctypes.c_uint, ctypes.c_void_p, handler_t, ctypes.c_void_p]
+    lib.hs_free_scratch.argtypes = [ctypes.c_void_p]
+    lib.hs_free_database.argtypes = [ctypes.c_void_p]
+    lib.hs_free_compile_error.argtypes = [ctypes.c_void_p]
+    rc = lib.hs_compile_multi(pa, fa, ia, n, 1, None, ctypes.byref(db), ctypes.byref(err))
+    lib.hs_free_compile_error(err)
+    assert rc == 0
+    assert lib.hs_alloc_scratch(db, ctypes.byref(scratch)) == 0
+    out = []
+    for block in blocks:
+        events = []
+
+        def on_event(id_, from_, to, flags_, ctx, events=events):
+            events.append((id_, to))
+            return 0
+
+        assert lib.hs_scan(db, block, len(block), 0, scratch, handler_t(on_event), None) == 0
+        out.append(events)
+    lib.hs_free_scratch(scratch)
+    lib.hs_free_database(db)
+    return out
+
+
+def test_face_a_hs_scan_matches_oracle(torch_cuda):
+    import ctypes
+
+    from hypergrep_amd import utils
+
+    product = utils._get_hyperscanner_lib()
+    oracle = ctypes.CDLL(os.path.join(oracle_py.ORACLE_DIR, "_build", "libhs.so.5"))
+    patterns = ["needle_in_haystack", "fo+bar", "^begin", "end$", "a.c", "\\bword\\b", "(?i)CaseLess_Long_Literal", "x"]
+    flags = [14, 14, 14, 14, 6, 10, 14, 6]
+    ids = [0, 1, 2, 3, 4, 5, 6, 7]
+    blocks = [b"foobar\n", b"begin with needle_in_haystack and end\n", b"two\nbegin lines end\nneedle_in_haystack", b"a\nc abc word\n",
+              b"xx caseless_long_literal CASELESS_LONG_LITERAL\n", b"\0x\0needle_in_haystack\n", b"q" * 40000 + b"needle_in_haystack" + b"z" * 100]
+    got = _hs_events(product, patterns, flags, ids, blocks)
+    want = _hs_events(oracle, patterns, flags, ids, blocks)
+    assert got == want
+    assert any(len(e) > 2 for e in want)
+    # early termination: a handler that returns non-zero stops the scan with HS_SCAN_TERMINATED (-3)
+    handler_t = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_uint, ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_uint, ctypes.c_void_p)
+    n = 1
+    pa = (ctypes.c_char_p * n)(b"a")
+    fa = (ctypes.c_uint * n)(6)
+    ia = (ctypes.c_uint * n)(0)
+    db, scratch = ctypes.c_void_p(), ctypes.c_void_p()
+    assert product.hs_compile_multi(pa, fa, ia, n, 1, None, ctypes.byref(db), None) == 0
+    assert product.hs_alloc_scratch(db, ctypes.byref(scratch)) == 0
+    seen = []
+    assert product.hs_scan(db, b"aaaa", 4, 0, scratch, handler_t(lambda i, f, t, fl, c: seen.append(t) or 1), None) == -3
+    assert seen == [1]
+    product.hs_free_scratch(scratch)
+    product.hs_free_database(db)
+    bad = ctypes.POINTER(_HsErr)()
+    assert product.hs_compile_multi((ctypes.c_char_p * 1)(b"(?<!a)b"), fa, ia, 1, 1, None, ctypes.byref(db), ctypes.byref(bad)) == -4
+    assert bad.contents.expression == 0 and bad.contents.message
+    product.hs_free_compile_error(bad)
