@@ -946,6 +946,15 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
         for (uint32_t v : nodes_of[e.first.first]) setbit(p.follow_off + v * nw, to);
       }
       db->max_nw = std::max(db->max_nw, nw);
+      if (nw == 1) {  // context-free single-word automaton: the confirm kernel's fast path
+        bool simple = true;
+        const uint32_t full = nn == 32 ? 0xFFFFFFFFu : ((1u << nn) - 1u);
+        for (uint32_t i = 0; i < 16; i++) simple = simple && db->pool[p.amask_off + i] == full;
+        for (uint32_t i = 1; i < 20; i++) simple = simple && db->pool[p.acc_off + i] == db->pool[p.acc_off];
+        p.simple = simple ? 1 : 0;
+        p.acc_all = db->pool[p.acc_off];
+        p.init_word = db->pool[p.init_off];
+      }
 
       // required literals
       Info info = analyze(*root);
@@ -955,6 +964,7 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
       bool fast = !cover.empty() && min_len(cover) >= HG_FAST_MIN_FACTOR;
       // a literal containing '\n' before its last byte can never lie inside one line; keep such patterns always-on
       p.tier = fast ? 0 : 1;
+      if (fast) ((p.simple && p.single) ? db->n_fast_confirm : db->n_generic_confirm)++;
       if (fast) {
         covers[cur].lits = cover;
         for (auto &l : cover)

@@ -1,0 +1,131 @@
+// Device-only fast paths of the confirm stage (hg_confirm_kernel).  Semantics are exactly those of the scalar
+// reference routines in hg_core.h (hg_verify_window, hg_confirm), which stay in use for multi-word / assertion
+// patterns and are what the host tests replay; here the same work is arranged for memory latency:
+//   * the literal verify compares 4 bytes at a time from aligned dword loads,
+//   * the line is located and scanned in aligned 16-byte chunks (SWAR newline / NUL detection),
+//   * for "simple" patterns (one state word, no boundary conditions) the automaton step needs only reach[c],
+//     whose 16 loads per chunk are independent, and the follow table, which is staged in LDS per lane.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "hg_core.h"
+
+namespace hgdev {
+
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *text, uint64_t off) {
+  const uint32_t *p = reinterpret_cast<const uint32_t *>(text + (off & ~3ull));
+  const uint32_t sh = static_cast<uint32_t>(off & 3u) * 8u;
+  const uint32_t lo = p[0];
+  if (sh == 0) return lo;
+  return (lo >> sh) | (p[1] << (32u - sh));
+}
+
+// hg_verify_window with dword compares.  The text buffer is readable up to nbytes rounded up to 16.
+template <typename Emit>
+__device__ __forceinline__ void verify_window(const HgDbView &db, const uint8_t *text, uint64_t nbytes, uint64_t pos, uint32_t w, Emit &&emit) {
+  const uint32_t folded = w | db.fold_mask;
+  const uint32_t h = hg_hash_window(folded);
+  for (uint32_t j = db.bucket_off[h], e = db.bucket_off[h + 1]; j < e; j++) {
+    const HgWindow win = db.windows[j];
+    if (win.value != folded) continue;
+    const uint32_t off = win.factor_off & 0xff;
+    const HgFactor *f = &db.factors[win.factor_off >> 8];
+    const uint32_t len = f->len;
+    if (pos < off) continue;
+    const uint64_t start = pos - off;
+    if (start + len > nbytes) continue;
+    const uint32_t *lit = reinterpret_cast<const uint32_t *>(f->lit), *cm = reinterpret_cast<const uint32_t *>(f->cmask);
+    uint32_t diff = 0;
+    for (uint32_t b = 0; b < len; b += 4) {
+      uint32_t keep = len - b >= 4 ? 0xFFFFFFFFu : ((1u << ((len - b) * 8)) - 1u);
+      diff |= (load_u32_unaligned(text, start + b) ^ lit[b >> 2]) & cm[b >> 2] & keep;
+    }
+    if (diff == 0) emit(f->pattern);
+  }
+}
+
+__device__ __forceinline__ uint32_t byte_of(const uint4 &v, uint32_t i) {
+  const uint32_t w = i < 8 ? (i < 4 ? v.x : v.y) : (i < 12 ? v.z : v.w);
+  return (w >> ((i & 3u) * 8u)) & 0xFFu;
+}
+// 16-bit mask of the bytes of v equal to `c`
+__device__ __forceinline__ uint32_t eq_mask16(const uint4 &v, uint32_t c4) {
+  const uint32_t m0 = hg_zero_bytes(v.x ^ c4), m1 = hg_zero_bytes(v.y ^ c4), m2 = hg_zero_bytes(v.z ^ c4), m3 = hg_zero_bytes(v.w ^ c4);
+  auto pack = [](uint32_t m) { return ((m >> 7) & 1u) | ((m >> 14) & 2u) | ((m >> 21) & 4u) | ((m >> 28) & 8u); };
+  return pack(m0) | (pack(m1) << 4) | (pack(m2) << 8) | (pack(m3) << 12);
+}
+
+// Start of the line containing `pos` when the previous '\n' lies in [tile_start, pos) (rank > 0).
+__device__ __forceinline__ uint64_t line_start_in_tile(const uint8_t *text, uint64_t tile_start, uint64_t pos) {
+  uint64_t chunk = (pos - 1) & ~15ull;
+  for (;;) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(text + chunk);
+    uint32_t m = eq_mask16(v, 0x0a0a0a0au);
+    if (chunk + 16 > pos) m &= (1u << static_cast<uint32_t>(pos - chunk)) - 1u;  // only bytes before pos
+    if (m) return chunk + (31 - __clz(m)) + 1;
+    if (chunk <= tile_start) return tile_start;  // cannot happen for rank > 0
+    chunk -= 16;
+  }
+}
+
+// Confirm one (candidate, pattern) for a "simple" SINGLEMATCH pattern.  follow_lds: this lane's private LDS slot
+// (entries interleaved by lane: index v * 64).  Reports at most one hit: the smallest match end offset.
+template <typename Emit>
+__device__ __forceinline__ void confirm_simple(const HgDbView &db, const uint8_t *text, uint64_t nbytes, const HgTileSum *sums, const HgTileBase *bases,
+                                               uint64_t bs1, uint64_t pos, const HgPattern &p, uint32_t rank, uint32_t *follow_lds, Emit &&emit) {
+  const uint64_t t = pos >> HG_TILE_SHIFT, tile_start = t << HG_TILE_SHIFT;
+  const uint64_t s = rank == 0 ? bases[t].cs : line_start_in_tile(text, tile_start, pos);
+  const uint64_t k = (pos - s) / bs1;
+  const uint64_t ps = s + k * bs1;
+  const uint64_t line_no = hg_line_index(text, sums[t], bases[t], tile_start, rank, s, bs1, bs1 < HG_TILE_BYTES) + k;
+  const uint64_t limit = ps + bs1 < nbytes ? ps + bs1 : nbytes;
+
+  const uint32_t *reach = db.pool + p.reach_off, *follow = db.pool + p.follow_off;
+  for (uint32_t v = 0; v < p.nnodes; v++) follow_lds[v * 64] = follow[v];
+  const uint32_t init = p.init_word, acc = p.acc_all;
+
+  // leading NULs are skipped (hyperscanner.c:207-214): a = first non-NUL byte of the piece
+  uint64_t a = ps;
+  while (a < limit && text[a] == 0) a++;
+  if (a >= limit) return;  // empty or all-NUL piece
+
+  uint32_t S = 0, first_to = HG_NONE32;
+  uint64_t z = limit;
+  for (uint64_t chunk = a & ~15ull; chunk < limit; chunk += 16) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(text + chunk);
+    const uint32_t lo = chunk < a ? static_cast<uint32_t>(a - chunk) : 0u;
+    const uint32_t hi = limit - chunk < 16 ? static_cast<uint32_t>(limit - chunk) : 16u;
+    const uint32_t below_lo = (1u << lo) - 1u;
+    const uint32_t nl = eq_mask16(v, 0x0a0a0a0au) & ~below_lo, nul = eq_mask16(v, 0u) & ~below_lo;
+    // bytes [lo, end) of this chunk belong to the scanned line; the piece ends inside the chunk if stop
+    uint32_t end = hi;
+    bool stop = false;
+    const uint32_t stops = (nl | nul) & ((1u << hi) - 1u);
+    if (stops) {
+      const uint32_t e = __ffs(stops) - 1;
+      end = ((nl >> e) & 1u) ? e + 1 : e;  // a newline is part of the line, a NUL is not
+      stop = true;
+    }
+    if (first_to == HG_NONE32) {
+      uint32_t r[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) r[i] = reach[byte_of(v, i)];  // 16 independent loads
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        if (static_cast<uint32_t>(i) >= lo && static_cast<uint32_t>(i) < end && first_to == HG_NONE32) {
+          uint32_t T = init;
+          for (uint32_t x = S; x; x &= x - 1) T |= follow_lds[(__ffs(x) - 1) * 64];
+          S = T & r[i];
+          if (S & acc) first_to = static_cast<uint32_t>(chunk + i + 1 - a);
+        }
+      }
+    }
+    if (stop || hi < 16) {
+      z = chunk + end;
+      break;
+    }
+  }
+  if (first_to != HG_NONE32) emit(line_no, first_to, a, static_cast<uint32_t>(z - a));
+}
+
+}  // namespace hgdev

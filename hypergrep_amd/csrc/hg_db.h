@@ -61,7 +61,10 @@ struct HgPattern {
   uint32_t acc_off;     // acc[4][5][nw]    nodes that accept for (ctx of own byte, next ctx)
   uint32_t tier;        // 0: anchored by a required literal (stream prefilter + confirm); 1: always-on
   uint32_t single;      // HS_FLAG_SINGLEMATCH set
-  uint32_t pad[5];
+  uint32_t simple;      // one state word and no boundary conditions: S' = (init | follow(S)) & reach[c], accept = S & acc_all
+  uint32_t acc_all;     // accepting nodes when `simple`
+  uint32_t init_word;   // init[0] when `simple`
+  uint32_t pad[2];
 };
 static_assert(sizeof(HgPattern) == 64, "HgPattern layout");
 

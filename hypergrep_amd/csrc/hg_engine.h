@@ -10,6 +10,7 @@
 #include "hg_post.h"
 
 // device counters: totals, and the largest per-segment demand seen when a private segment overflowed
+constexpr uint32_t HG_CONFIRM_SPLIT = 4;  // confirm blocks per candidate segment
 enum { HG_CNT_CANDS = 0, HG_CNT_HITS = 1, HG_CNT_CAND_NEED = 2, HG_CNT_HIT_NEED = 3, HG_CNT_WORDS = 8 };
 
 struct HgStreamArgs {

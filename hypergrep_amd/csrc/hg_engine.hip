@@ -20,6 +20,7 @@ __global__ void hg_tile_spine_kernel(const HgTileElem *agg, uint32_t nblocks, ui
 __global__ void hg_tile_apply_kernel(const HgTileSum *sums, uint64_t ntiles, uint64_t bs1, const HgTileBase *block_base, HgTileBase *bases);
 __global__ void hg_tile_inner_kernel(const uint8_t *text, HgTileSum *sums, uint64_t ntiles, uint64_t bs1);
 __global__ void hg_confirm_kernel(HgConfirmArgs a);
+__global__ void hg_confirm_generic_kernel(HgConfirmArgs a);
 __global__ void hg_always_on_kernel(HgConfirmArgs a);
 __global__ void hg_block_mark_kernel(HgConfirmArgs a, uint32_t *pattern_flags);
 __global__ void hg_block_scan_kernel(HgConfirmArgs a, const uint32_t *pattern_flags);
@@ -247,9 +248,10 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       hipLaunchKernelGGL(hg_block_scan_kernel, dim3(always_blocks), dim3(256), 0, stream, ca, d_pflags_);
       HG_TRY(hipGetLastError(), "block-mode launch");
     } else if (db_->patterns.size() > db_->slow.size()) {
-      confirm_blocks = wgs;  // block b consumes candidate segment b
+      confirm_blocks = wgs * HG_CONFIRM_SPLIT;  // HG_CONFIRM_SPLIT blocks share candidate segment b
       ca.hit_seg_cap = hit_cap_ / confirm_blocks;
-      hipLaunchKernelGGL(hg_confirm_kernel, dim3(confirm_blocks), dim3(256), 0, stream, ca);
+      if (db_->n_fast_confirm) hipLaunchKernelGGL(hg_confirm_kernel, dim3(confirm_blocks), dim3(256), 0, stream, ca);
+      if (db_->n_generic_confirm) hipLaunchKernelGGL(hg_confirm_generic_kernel, dim3(confirm_blocks), dim3(256), 0, stream, ca);
       HG_TRY(hipGetLastError(), "hg_confirm_kernel launch");
     }
     if (!block_mode && !db_->slow.empty()) {

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 
+#include "hg_confirm_dev.h"
 #include "hg_core.h"
 #include "hg_engine.h"
 #include "hg_post.h"
@@ -461,25 +462,59 @@ __device__ __forceinline__ void flush_hits(const HgConfirmArgs &a, uint32_t *lds
   }
 }
 
-// One lane per window hit of the stream pass; block b consumes segment b of the candidate buffer.
-__global__ __launch_bounds__(256) void hg_confirm_kernel(HgConfirmArgs a) {
+// One lane per window hit of the stream pass.  Candidate segment s (written by stream workgroup s) is consumed by
+// the CONFIRM_SPLIT blocks s*CONFIRM_SPLIT .. +CONFIRM_SPLIT-1, so that even a few hundred thousand candidates
+// keep every CU busy: the work is all memory latency.
+template <bool SIMPLE>
+__device__ __forceinline__ void confirm_body(const HgConfirmArgs &a) {
   __shared__ uint32_t s_n, s_base;
+  __shared__ uint32_t s_follow[SIMPLE ? 32 * 256 : 1];  // per lane: the follow table of its pattern (interleaved by lane within a wave)
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
   const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
   const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n};
-  const HgCand *cseg = a.cands + static_cast<uint64_t>(blockIdx.x) * a.cand_seg_cap;
-  const uint32_t n = a.seg_count[blockIdx.x];
-  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+  const uint32_t seg = blockIdx.x / HG_CONFIRM_SPLIT, sub = blockIdx.x % HG_CONFIRM_SPLIT;
+  const HgCand *cseg = a.cands + static_cast<uint64_t>(seg) * a.cand_seg_cap;
+  const uint32_t n = a.seg_count[seg];
+  uint32_t *follow_lds = SIMPLE ? s_follow + (threadIdx.x >> 6) * (32 * 64) + (threadIdx.x & 63u) : s_follow;
+  for (uint32_t i = sub * blockDim.x + threadIdx.x; i < n; i += HG_CONFIRM_SPLIT * blockDim.x) {
     const HgCand c = cseg[i];
-    hg_verify_window(a.db, a.text, a.nbytes, c.pos, c.word, [&](uint32_t pattern) {
-      const uint32_t id = a.db.patterns[pattern].id;
-      hg_confirm(a.db, a.text, a.nbytes, a.sums, a.bases, a.bs1, c.pos, pattern, c.rank,
-                 [&](uint64_t line_no, uint32_t to, uint64_t start, uint32_t len) { sink.push(line_no, id, to, start, len, pattern); });
+    // collect the patterns whose literal is really there first, then confirm them slot by slot: lanes stay converged
+    // in the (long) confirm code instead of entering it at different bucket positions
+    uint32_t found[4] = {HG_NONE32, HG_NONE32, HG_NONE32, HG_NONE32};
+    uint32_t nfound = 0;
+    auto confirm_one = [&](uint32_t pattern) {
+      const HgPattern &p = a.db.patterns[pattern];
+      const uint32_t id = p.id;
+      auto emit = [&](uint64_t line_no, uint32_t to, uint64_t start, uint32_t len) { sink.push(line_no, id, to, start, len, pattern); };
+      const bool fast = p.simple && p.single;
+      if (SIMPLE) {
+        if (fast) hgdev::confirm_simple(a.db, a.text, a.nbytes, a.sums, a.bases, a.bs1, c.pos, p, c.rank, follow_lds, emit);
+      } else {
+        if (!fast) hg_confirm(a.db, a.text, a.nbytes, a.sums, a.bases, a.bs1, c.pos, pattern, c.rank, emit);
+      }
+    };
+    hgdev::verify_window(a.db, a.text, a.nbytes, c.pos, c.word, [&](uint32_t pattern) {
+      if (nfound < 4) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (static_cast<uint32_t>(q) == nfound) found[q] = pattern;
+        nfound++;
+      } else {
+        confirm_one(pattern);  // more than four literals share this window: rare
+      }
     });
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (found[q] != HG_NONE32) confirm_one(found[q]);
   }
   flush_hits(a, &s_n, &s_base);
 }
+// Two launches over the same candidates: context-free single-word SINGLEMATCH patterns take the latency-optimised
+// path (few registers, high occupancy); everything else (assertions, multi-word state, all-matches mode) takes the
+// scalar reference routine.
+__global__ __launch_bounds__(256) void hg_confirm_kernel(HgConfirmArgs a) { confirm_body<true>(a); }
+__global__ __launch_bounds__(256) void hg_confirm_generic_kernel(HgConfirmArgs a) { confirm_body<false>(a); }
 
 // Always-on tier: one wave per tile, each lane owns 256 bytes and handles the lines that START there.
 __global__ __launch_bounds__(256) void hg_always_on_kernel(HgConfirmArgs a) {
