@@ -9,6 +9,7 @@
 // empty string (no HS_FLAG_ALLOWEMPTY), embedded start/end anchors outside multiline mode, and flag
 // bits other than CASELESS|DOTALL|MULTILINE|SINGLEMATCH.  Byte semantics throughout (no UTF-8 mode).
 #include "hg_compile.h"
+#include "hg_core.h"
 
 #include <algorithm>
 #include <array>
@@ -585,6 +586,12 @@ void check_embedded_anchors(const Node &n, bool before, bool after) {
   }
 }
 
+bool has_assert(const Node &n) {
+  if (n.kind == Node::Assert) return true;
+  for (auto &k : n.kids) if (has_assert(*k)) return true;
+  return false;
+}
+
 // ---------------------------------------------------------------- position automaton
 struct Cond { uint32_t pos, tt; };
 struct Frag {
@@ -964,7 +971,17 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
       bool fast = !cover.empty() && min_len(cover) >= HG_FAST_MIN_FACTOR;
       // a literal containing '\n' before its last byte can never lie inside one line; keep such patterns always-on
       p.tier = fast ? 0 : 1;
-      if (fast) ((p.simple && p.single) ? db->n_fast_confirm : db->n_generic_confirm)++;
+      // literal-only: the expression's language is exactly one literal that fits the factor record, has no NUL
+      // or inner newline, and no assertions -> a verified factor occurrence is a match
+      if (fast && info.exact && info.set.size() == 1 && cover.size() == 1 && info.set[0].bytes.size() <= HG_FACTOR_MAX &&
+          cover[0] == info.set[0] && !has_assert(*root)) {
+        const std::string &lb = info.set[0].bytes;
+        bool clean = true;
+        for (size_t j = 0; j < lb.size(); j++)
+          if (lb[j] == 0 || (lb[j] == '\n' && j + 1 < lb.size())) clean = false;
+        p.literal_only = clean ? 1 : 0;
+      }
+      if (fast) db->n_confirm_mode[hg_confirm_mode(p)]++;
       if (fast) {
         covers[cur].lits = cover;
         for (auto &l : cover)

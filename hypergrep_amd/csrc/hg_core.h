@@ -75,10 +75,23 @@ HG_HD uint32_t hg_ctz(uint32_t x) {
 #endif
 }
 
+// Which confirm routine handles a pattern:
+//   0  literal-only SINGLEMATCH expression: the verified literal occurrence is the match (no automaton run)
+//   1  context-free single-word SINGLEMATCH automaton (follow table in LDS)
+//   2  SINGLEMATCH automaton with <= 2 state words, boundary conditions allowed
+//   3  everything else (scalar reference routine)
+constexpr uint32_t HG_CONFIRM_MODES = 4;
+HG_HD uint32_t hg_confirm_mode(const HgPattern &p) {
+  if (p.single && p.literal_only) return 0;
+  if (p.single && p.simple) return 1;
+  if (p.single && p.nw <= 2) return 2;
+  return 3;
+}
+
 HG_HD uint32_t hg_prev_ctx(uint32_t c) { return c == '\n' ? HG_PC_NL : (hg_is_word(c) ? HG_PC_WORD : HG_PC_OTHER); }
 
 // Bucket probe + literal verify for one window hit at absolute byte `pos` (dword aligned) holding raw
-// dword `w`.  Calls emit(pattern) for every factor whose literal really occurs around pos.
+// dword `w`.  Calls emit(pattern, literal start, literal length) for every factor whose literal really occurs around pos.
 template <typename Emit>
 HG_HD void hg_verify_window(const HgDbView &db, const uint8_t *text, uint64_t nbytes, uint64_t pos, uint32_t w,
                             Emit &&emit) {
@@ -96,7 +109,7 @@ HG_HD void hg_verify_window(const HgDbView &db, const uint8_t *text, uint64_t nb
     for (uint32_t b = 0; b < f.len; b++) {
       if ((text[start + b] ^ f.lit[b]) & f.cmask[b]) { ok = false; break; }
     }
-    if (ok) emit(f.pattern);
+    if (ok) emit(f.pattern, start, f.len);
   }
 }
 

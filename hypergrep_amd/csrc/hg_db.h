@@ -64,7 +64,8 @@ struct HgPattern {
   uint32_t simple;      // one state word and no boundary conditions: S' = (init | follow(S)) & reach[c], accept = S & acc_all
   uint32_t acc_all;     // accepting nodes when `simple`
   uint32_t init_word;   // init[0] when `simple`
-  uint32_t pad[2];
+  uint32_t literal_only;  // the whole expression is one literal (its factor): a verified occurrence IS the match
+  uint32_t pad[1];
 };
 static_assert(sizeof(HgPattern) == 64, "HgPattern layout");
 

@@ -10,7 +10,15 @@
 #include "hg_post.h"
 
 // device counters: totals, and the largest per-segment demand seen when a private segment overflowed
-constexpr uint32_t HG_CONFIRM_SPLIT = 4;  // confirm blocks per candidate segment
+constexpr uint32_t HG_CONFIRM_SPLIT = 4;   // verify blocks per candidate segment
+constexpr uint32_t HG_DEFER_SHARDS = 64;   // append-only lists of verified candidates that need an automaton run
+
+// A verified literal occurrence whose expression still needs its automaton: pattern may match in the line holding pos.
+struct HgDeferred {
+  uint64_t pos;
+  uint32_t pattern;
+  uint32_t rank;
+};
 enum { HG_CNT_CANDS = 0, HG_CNT_HITS = 1, HG_CNT_CAND_NEED = 2, HG_CNT_HIT_NEED = 3, HG_CNT_WORDS = 8 };
 
 struct HgStreamArgs {
@@ -39,7 +47,9 @@ struct HgConfirmArgs {
   HgHitAux *aux;
   HgHit *tmp_hits;  // gridDim x hit_seg_cap block-private staging
   HgHitAux *tmp_aux;
-  uint32_t cand_seg_cap, hit_cap, hit_seg_cap, pad;
+  HgDeferred *deferred;   // HG_DEFER_SHARDS x defer_shard_cap
+  uint32_t *defer_count;  // entries appended to each shard
+  uint32_t cand_seg_cap, hit_cap, hit_seg_cap, defer_shard_cap;
   uint32_t *counters;
 };
 
@@ -92,6 +102,8 @@ class HgScanner {
   HgTileBase *d_bases_ = nullptr, *d_block_base_ = nullptr, *d_final_ = nullptr;
   HgTileElem *d_agg_ = nullptr;
   HgCand *d_cands_ = nullptr;
+  HgDeferred *d_deferred_ = nullptr;
+  uint32_t *d_defer_count_ = nullptr;
   HgHit *d_hits_raw_ = nullptr, *d_hits_sorted_ = nullptr, *d_hits_out_ = nullptr;
   HgHitAux *d_aux_raw_ = nullptr, *d_aux_sorted_ = nullptr, *d_aux_out_ = nullptr;
   uint64_t *d_key_a_ = nullptr, *d_key_b_ = nullptr;

@@ -19,7 +19,9 @@ __global__ void hg_tile_spine_kernel(const HgTileElem *agg, uint32_t nblocks, ui
                                      HgTileBase *final_state);
 __global__ void hg_tile_apply_kernel(const HgTileSum *sums, uint64_t ntiles, uint64_t bs1, const HgTileBase *block_base, HgTileBase *bases);
 __global__ void hg_tile_inner_kernel(const uint8_t *text, HgTileSum *sums, uint64_t ntiles, uint64_t bs1);
+__global__ void hg_verify_kernel(HgConfirmArgs a);
 __global__ void hg_confirm_kernel(HgConfirmArgs a);
+__global__ void hg_confirm_ctx_kernel(HgConfirmArgs a);
 __global__ void hg_confirm_generic_kernel(HgConfirmArgs a);
 __global__ void hg_always_on_kernel(HgConfirmArgs a);
 __global__ void hg_block_mark_kernel(HgConfirmArgs a, uint32_t *pattern_flags);
@@ -99,7 +101,7 @@ int HgScanner::create(const HgDb *db, int device, HgScanner **out, std::string *
   HG_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_selected_), 16), "alloc counters");
   HG_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_final_), sizeof(HgTileBase)), "alloc state");
   HG_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_pflags_), db->patterns.size() * 4 + 16), "alloc pattern flags");
-  HG_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_counters_), (HG_CNT_WORDS + 4) * 4), "alloc pinned");
+  HG_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_counters_), (HG_CNT_WORDS + 4 + HG_DEFER_SHARDS) * 4), "alloc pinned");
   HG_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_final_), sizeof(HgTileBase)), "alloc pinned");
   for (auto &ev : s->ev_) HG_TRY(hipEventCreate(&ev), "hipEventCreate");
 #undef HG_TRY
@@ -111,7 +113,7 @@ HgScanner::~HgScanner() {
   (void)hipSetDevice(device_);
   void *ptrs[] = {d_patterns_, d_pool_, d_factors_, d_windows_, d_bucket_, d_filter_, d_ext_, d_slow_, d_sums_, d_bases_, d_block_base_,
                   d_final_, d_agg_, d_cands_, d_hits_raw_, d_hits_sorted_, d_hits_out_, d_aux_raw_, d_aux_sorted_, d_aux_out_,
-                  d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, d_keep_, d_counters_, d_selected_, d_temp_, d_seg_count_, d_pflags_};
+                  d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, d_keep_, d_counters_, d_selected_, d_temp_, d_seg_count_, d_pflags_, d_deferred_, d_defer_count_};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (h_counters_) (void)hipHostFree(h_counters_);
@@ -125,6 +127,9 @@ int HgScanner::alloc_cands(uint64_t n) {
   if (d_cands_) (void)hipFree(d_cands_);
   d_cands_ = nullptr;
   if (fail(hipMalloc(reinterpret_cast<void **>(&d_cands_), n * sizeof(HgCand)), "workspace alloc (candidates)")) return HG_ERR_HIP;
+  if (d_deferred_) (void)hipFree(d_deferred_);
+  d_deferred_ = nullptr;
+  if (fail(hipMalloc(reinterpret_cast<void **>(&d_deferred_), n * sizeof(HgDeferred)), "workspace alloc (deferred)")) return HG_ERR_HIP;
   cand_cap_ = static_cast<uint32_t>(n);
   return HG_OK;
 }
@@ -167,7 +172,7 @@ int HgScanner::ensure(uint64_t nbytes) {
   }
   if (!d_seg_count_) {
     max_segs_ = static_cast<uint32_t>(num_cus_) * 16;
-    if (re(d_seg_count_, max_segs_)) return HG_ERR_HIP;
+    if (re(d_seg_count_, max_segs_) || re(d_defer_count_, HG_DEFER_SHARDS)) return HG_ERR_HIP;
   }
   // one candidate / hit per KiB of text to start with; grows (and the pass repeats) on overflow
   uint64_t want = std::max<uint64_t>(nbytes / 1024, 1u << 16);
@@ -250,8 +255,15 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
     } else if (db_->patterns.size() > db_->slow.size()) {
       confirm_blocks = wgs * HG_CONFIRM_SPLIT;  // HG_CONFIRM_SPLIT blocks share candidate segment b
       ca.hit_seg_cap = hit_cap_ / confirm_blocks;
-      if (db_->n_fast_confirm) hipLaunchKernelGGL(hg_confirm_kernel, dim3(confirm_blocks), dim3(256), 0, stream, ca);
-      if (db_->n_generic_confirm) hipLaunchKernelGGL(hg_confirm_generic_kernel, dim3(confirm_blocks), dim3(256), 0, stream, ca);
+      ca.deferred = d_deferred_;
+      ca.defer_count = d_defer_count_;
+      ca.defer_shard_cap = cand_cap_ / HG_DEFER_SHARDS;
+      HG_TRY(hipMemsetAsync(d_defer_count_, 0, HG_DEFER_SHARDS * 4, stream), "memset deferred counts");
+      hipLaunchKernelGGL(hg_verify_kernel, dim3(confirm_blocks), dim3(256), 0, stream, ca);
+      if (db_->n_confirm_mode[1]) hipLaunchKernelGGL(hg_confirm_kernel, dim3(confirm_blocks), dim3(256), 0, stream, ca);
+      if (db_->n_confirm_mode[2]) hipLaunchKernelGGL(hg_confirm_ctx_kernel, dim3(confirm_blocks), dim3(256), 0, stream, ca);
+      if (db_->n_confirm_mode[3]) hipLaunchKernelGGL(hg_confirm_generic_kernel, dim3(confirm_blocks), dim3(256), 0, stream, ca);
+      HG_TRY(hipMemcpyAsync(h_counters_ + HG_CNT_WORDS + 4, d_defer_count_, HG_DEFER_SHARDS * 4, hipMemcpyDeviceToHost, stream), "copy deferred counts");
       HG_TRY(hipGetLastError(), "hg_confirm_kernel launch");
     }
     if (!block_mode && !db_->slow.empty()) {
@@ -272,10 +284,15 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
 
   const uint64_t n_cands = h_counters_[HG_CNT_CANDS], n_raw = h_counters_[HG_CNT_HITS];
   const uint64_t cand_need = h_counters_[HG_CNT_CAND_NEED], hit_need = h_counters_[HG_CNT_HIT_NEED];
-  if (cand_need || hit_need || n_raw > hit_cap_) {
+  uint64_t defer_need = 0;
+  if (ntiles && !block_mode && db_->patterns.size() > db_->slow.size())
+    for (uint32_t i = 0; i < HG_DEFER_SHARDS; i++)
+      if (h_counters_[HG_CNT_WORDS + 4 + i] > cand_cap_ / HG_DEFER_SHARDS) defer_need = std::max<uint64_t>(defer_need, h_counters_[HG_CNT_WORDS + 4 + i]);
+  if (cand_need || defer_need || hit_need || n_raw > hit_cap_) {
     // a private segment (or the compact hit array) was too small: grow and let the caller repeat the pass
-    if (cand_need) {
-      uint64_t want = (cand_need + cand_need / 4 + 64) * wgs;
+    if (cand_need || defer_need) {
+      uint64_t want = std::max<uint64_t>((cand_need + cand_need / 4 + 64) * wgs, (defer_need + defer_need / 4 + 64) * HG_DEFER_SHARDS);
+      want = std::max<uint64_t>(want, static_cast<uint64_t>(cand_cap_) * 2);
       if (want > 0x7FFFFFF0u) {
         err_ = "more than 2^31 candidates in one scan call: split the buffer";
         return HG_ERR_ARG;

@@ -465,10 +465,12 @@ __device__ __forceinline__ void flush_hits(const HgConfirmArgs &a, uint32_t *lds
 // One lane per window hit of the stream pass.  Candidate segment s (written by stream workgroup s) is consumed by
 // the CONFIRM_SPLIT blocks s*CONFIRM_SPLIT .. +CONFIRM_SPLIT-1, so that even a few hundred thousand candidates
 // keep every CU busy: the work is all memory latency.
-template <bool SIMPLE>
-__device__ __forceinline__ void confirm_body(const HgConfirmArgs &a) {
+// Verify pass: one lane per window hit of the stream pass.  Candidate segment s (written by stream workgroup s) is
+// consumed by the HG_CONFIRM_SPLIT blocks s*HG_CONFIRM_SPLIT .. +HG_CONFIRM_SPLIT-1, so that even a few hundred
+// thousand candidates keep every CU busy (the work is all memory latency).  Literal-only expressions are finished
+// here; the other verified (position, pattern) pairs go to HG_DEFER_SHARDS append-only lists for the automaton passes.
+__global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
   __shared__ uint32_t s_n, s_base;
-  __shared__ uint32_t s_follow[SIMPLE ? 32 * 256 : 1];  // per lane: the follow table of its pattern (interleaved by lane within a wave)
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
   const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
@@ -476,45 +478,63 @@ __device__ __forceinline__ void confirm_body(const HgConfirmArgs &a) {
   const uint32_t seg = blockIdx.x / HG_CONFIRM_SPLIT, sub = blockIdx.x % HG_CONFIRM_SPLIT;
   const HgCand *cseg = a.cands + static_cast<uint64_t>(seg) * a.cand_seg_cap;
   const uint32_t n = a.seg_count[seg];
-  uint32_t *follow_lds = SIMPLE ? s_follow + (threadIdx.x >> 6) * (32 * 64) + (threadIdx.x & 63u) : s_follow;
+  const uint32_t shard = blockIdx.x % HG_DEFER_SHARDS;
+  HgDeferred *dlist = a.deferred + static_cast<uint64_t>(shard) * a.defer_shard_cap;
   for (uint32_t i = sub * blockDim.x + threadIdx.x; i < n; i += HG_CONFIRM_SPLIT * blockDim.x) {
     const HgCand c = cseg[i];
-    // collect the patterns whose literal is really there first, then confirm them slot by slot: lanes stay converged
-    // in the (long) confirm code instead of entering it at different bucket positions
-    uint32_t found[4] = {HG_NONE32, HG_NONE32, HG_NONE32, HG_NONE32};
-    uint32_t nfound = 0;
-    auto confirm_one = [&](uint32_t pattern) {
+    hgdev::verify_window(a.db, a.text, a.nbytes, c.pos, c.word, [&](uint32_t pattern, uint64_t fs, uint32_t len) {
       const HgPattern &p = a.db.patterns[pattern];
-      const uint32_t id = p.id;
-      auto emit = [&](uint64_t line_no, uint32_t to, uint64_t start, uint32_t len) { sink.push(line_no, id, to, start, len, pattern); };
-      const bool fast = p.simple && p.single;
-      if (SIMPLE) {
-        if (fast) hgdev::confirm_simple(a.db, a.text, a.nbytes, a.sums, a.bases, a.bs1, c.pos, p, c.rank, follow_lds, emit);
+      if (hg_confirm_mode(p) == 0) {
+        const uint32_t id = p.id;
+        hgdev::confirm_literal(a.text, a.nbytes, a.sums, a.bases, a.bs1, c.pos, c.rank, fs, len,
+                               [&](uint64_t line_no, uint32_t to, uint64_t start, uint32_t l) { sink.push(line_no, id, to, start, l, pattern); });
       } else {
-        if (!fast) hg_confirm(a.db, a.text, a.nbytes, a.sums, a.bases, a.bs1, c.pos, pattern, c.rank, emit);
-      }
-    };
-    hgdev::verify_window(a.db, a.text, a.nbytes, c.pos, c.word, [&](uint32_t pattern) {
-      if (nfound < 4) {
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-          if (static_cast<uint32_t>(q) == nfound) found[q] = pattern;
-        nfound++;
-      } else {
-        confirm_one(pattern);  // more than four literals share this window: rare
+        const uint32_t slot = atomicAdd(&a.defer_count[shard], 1u);  // wave-aggregated by the compiler; HG_DEFER_SHARDS addresses
+        if (slot < a.defer_shard_cap) dlist[slot] = HgDeferred{c.pos, pattern, c.rank};
       }
     });
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-      if (found[q] != HG_NONE32) confirm_one(found[q]);
   }
   flush_hits(a, &s_n, &s_base);
 }
-// Two launches over the same candidates: context-free single-word SINGLEMATCH patterns take the latency-optimised
-// path (few registers, high occupancy); everything else (assertions, multi-word state, all-matches mode) takes the
-// scalar reference routine.
-__global__ __launch_bounds__(256) void hg_confirm_kernel(HgConfirmArgs a) { confirm_body<true>(a); }
-__global__ __launch_bounds__(256) void hg_confirm_generic_kernel(HgConfirmArgs a) { confirm_body<false>(a); }
+
+// Automaton passes over the deferred lists, one launch per confirm mode present in the database so that lanes of a
+// wave run the same routine and the common modes keep a small register footprint:
+//   MODE 1 context-free single-word automaton (follow table in LDS), MODE 2 <= 2 state words with boundary conditions,
+//   MODE 3 the scalar reference routine (multi-word state, all-matches mode).
+template <int MODE>
+__device__ __forceinline__ void confirm_body(const HgConfirmArgs &a) {
+  __shared__ uint32_t s_n, s_base;
+  __shared__ uint32_t s_follow[MODE == 1 ? 32 * 256 : 1];
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
+  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n};
+  uint32_t *follow_lds = MODE == 1 ? s_follow + (threadIdx.x >> 6) * (32 * 64) + (threadIdx.x & 63u) : s_follow;
+  // block b walks shard b % HG_DEFER_SHARDS with the blocks that share it
+  const uint32_t shard = blockIdx.x % HG_DEFER_SHARDS, peer = blockIdx.x / HG_DEFER_SHARDS, peers = (gridDim.x + HG_DEFER_SHARDS - 1 - shard) / HG_DEFER_SHARDS;
+  const HgDeferred *dlist = a.deferred + static_cast<uint64_t>(shard) * a.defer_shard_cap;
+  uint32_t n = a.defer_count[shard];
+  if (n > a.defer_shard_cap) n = a.defer_shard_cap;
+  for (uint32_t i = peer * blockDim.x + threadIdx.x; i < n; i += peers * blockDim.x) {
+    const HgDeferred d = dlist[i];
+    const HgPattern &p = a.db.patterns[d.pattern];
+    if (hg_confirm_mode(p) != MODE) continue;
+    const uint32_t id = p.id, pattern = d.pattern;
+    auto emit = [&](uint64_t line_no, uint32_t to, uint64_t start, uint32_t len) { sink.push(line_no, id, to, start, len, pattern); };
+    if (MODE == 1) {
+      hgdev::confirm_simple(a.db, a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, p, d.rank, follow_lds, emit);
+    } else if (MODE == 2) {
+      if (p.nw == 1) hgdev::confirm_ctx<1>(a.db, a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, p, d.rank, emit);
+      else hgdev::confirm_ctx<2>(a.db, a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, p, d.rank, emit);
+    } else {
+      hg_confirm(a.db, a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, pattern, d.rank, emit);
+    }
+  }
+  flush_hits(a, &s_n, &s_base);
+}
+__global__ __launch_bounds__(256) void hg_confirm_kernel(HgConfirmArgs a) { confirm_body<1>(a); }
+__global__ __launch_bounds__(256) void hg_confirm_ctx_kernel(HgConfirmArgs a) { confirm_body<2>(a); }
+__global__ __launch_bounds__(256) void hg_confirm_generic_kernel(HgConfirmArgs a) { confirm_body<3>(a); }
 
 // Always-on tier: one wave per tile, each lane owns 256 bytes and handles the lines that START there.
 __global__ __launch_bounds__(256) void hg_always_on_kernel(HgConfirmArgs a) {
@@ -554,7 +574,7 @@ __global__ __launch_bounds__(256) void hg_block_mark_kernel(HgConfirmArgs a, uin
   const uint32_t n = a.seg_count[blockIdx.x];
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
     const HgCand c = cseg[i];
-    hg_verify_window(a.db, a.text, a.nbytes, c.pos, c.word, [&](uint32_t pattern) { pattern_flags[pattern] = 1; });
+    hg_verify_window(a.db, a.text, a.nbytes, c.pos, c.word, [&](uint32_t pattern, uint64_t, uint32_t) { pattern_flags[pattern] = 1; });
   }
 }
 

@@ -152,7 +152,7 @@ long hgsim_scan(void *h, const uint8_t *data, uint64_t nbytes, int buffer_size, 
   std::vector<HgHitAux> aux;
   uint64_t verified = 0;
   for (auto &c : cands) {
-    hg_verify_window(v, data, nbytes, c.pos, c.word, [&](uint32_t pattern) {
+    hg_verify_window(v, data, nbytes, c.pos, c.word, [&](uint32_t pattern, uint64_t, uint32_t) {
       verified++;
       hg_confirm(v, data, nbytes, sums.data(), bases.data(), bs1, c.pos, pattern, c.rank,
                  [&](uint64_t line_no, uint32_t to, uint64_t a, uint32_t len) {
