@@ -40,7 +40,7 @@ def main() -> None:
     import torch
     import torch.distributed as dist
 
-    from hypergrep_amd import benchspec, device
+    from hypergrep_amd import benchspec, device, shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -70,8 +70,6 @@ def main() -> None:
     sc = device.Scanner(db, local_rank)
     stream = torch.cuda.current_stream().cuda_stream
 
-    counts = torch.zeros(2, dtype=torch.int64, device=dev)
-    gathered = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
     hit_buf = None
     recv_bufs: list = []
 
@@ -79,26 +77,15 @@ def main() -> None:
         st = sc.scan(text.data_ptr(), nbytes, stream=stream)
         if world > 1:
             nonlocal hit_buf, recv_bufs
-            counts[0] = st.n_lines
-            counts[1] = st.n_hits
-            dist.all_gather(gathered, counts)
-            totals = torch.stack(gathered).cpu()
-            line_off = int(totals[:rank, 0].sum())
+            totals = shard.exchange_counts(st.n_lines, st.n_hits, dev)
             # hit records (u64 line, u32 id, u32 to) -> a tensor, shard-local line numbers made global, sent to rank 0
             need = max(int(totals[:, 1].max()), 1)
             if hit_buf is None or hit_buf.shape[0] < need:
                 hit_buf = torch.empty((need + need // 8, 2), dtype=torch.int64, device=dev)
                 recv_bufs = [torch.empty_like(hit_buf) for _ in range(world - 1)] if rank == 0 else []
             n = sc.copy_hits_to(hit_buf.data_ptr(), st.n_hits, stream=stream)
-            hit_buf[:n, 0] += line_off
-            ops = []
-            if rank == 0:
-                for src in range(1, world):
-                    ops.append(dist.P2POp(dist.irecv, recv_bufs[src - 1][: int(totals[src, 1])], src))
-            else:
-                ops.append(dist.P2POp(dist.isend, hit_buf[:n], 0))
-            for w in dist.batch_isend_irecv(ops) if ops else []:
-                w.wait()
+            hit_buf[:n, 0] += shard.line_offset(totals, rank)
+            shard.gather_hits(hit_buf[:n], totals, recv_bufs)
         return st
 
     for _ in range(args.warmup):
@@ -155,6 +142,15 @@ def main() -> None:
             "pipeline": {"candidates": last.n_candidates, "raw_hits": last.n_raw_hits, "reruns": last.reruns,
                          "ms_total_device": round(last.ms_total, 4)},
         }
+        # HBM bytes per launch measured with PMC counters (tools/record_round.sh) for the same workload, if committed
+        try:
+            with open(os.path.join(REPO, "profiles", "hbm_traffic_latest.json"), encoding="utf-8") as f:
+                tr = json.load(f)
+            if tr["workload"] == args.workload and abs(tr["gib"] - args.gib) < 1e-9:
+                out["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = tr["source"]
+        except (OSError, KeyError, ValueError):
+            pass
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(text, nbytes, patterns, ids, sc, args.cpu_seconds)
         print(json.dumps(out), flush=True)
