@@ -44,6 +44,12 @@ int hg_db_compile(const char *const *expressions, const unsigned int *flags, con
   return HG_OK;
 }
 
+int hg_db_tune(hg_database_t *db, const void *sample, size_t nbytes) {
+  if (!db || (!sample && nbytes)) return HG_ERR_ARG;
+  std::string err;
+  return hgc_tune(db->db, static_cast<const uint8_t *>(sample), nbytes, &err) == 0 ? HG_OK : HG_ERR_COMPILE;
+}
+
 void hg_db_release(hg_database_t *db) {
   if (!db) return;
   hgc_free(db->db);
@@ -56,10 +62,8 @@ int hg_db_info(const hg_database_t *db, hg_db_info_t *info) {
   info->n_patterns = static_cast<uint32_t>(d.patterns.size());
   info->n_always_on = static_cast<uint32_t>(d.slow.size());
   info->n_literal_anchored = info->n_patterns - info->n_always_on;
-  uint32_t real_factors = 0;
-  for (auto &p : d.patterns) real_factors += p.tier == 0;
-  info->n_factors = real_factors ? static_cast<uint32_t>(d.factors.size()) : 0;
-  info->n_windows = real_factors ? static_cast<uint32_t>(d.windows.size()) : 0;
+  info->n_factors = d.nreal_factors;
+  info->n_windows = d.nreal_factors ? static_cast<uint32_t>(d.windows.size()) : 0;
   info->fold_mask = d.fold_mask;
   info->max_state_words = d.max_nw;
   info->table_bytes = static_cast<uint32_t>(d.pool.size() * 4);

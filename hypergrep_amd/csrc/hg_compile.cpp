@@ -18,6 +18,7 @@
 #include <map>
 #include <memory>
 #include <stdexcept>
+#include <unordered_map>
 
 namespace {
 
@@ -713,12 +714,6 @@ int byte_commonness(unsigned char b) {
   if (b > 32 && b < 127) return 2;
   return 1;
 }
-int window_score(const Lit &l, size_t off) {
-  int s = 0;
-  for (size_t i = 0; i < 4; i++) s += byte_commonness(static_cast<unsigned char>(l.bytes[off + i]));
-  return s;
-}
-
 size_t min_len(const LitSet &s) {
   size_t m = SIZE_MAX;
   for (auto &l : s) m = std::min(m, l.bytes.size());
@@ -767,7 +762,7 @@ Info analyze(const Node &n) {
       for (int b = 0; b < 256; b++) if (n.cls[b]) folded.set((b >= 'A' && b <= 'Z') ? b + 32 : b);
       bool case_closed = true;
       for (int b = 'a'; b <= 'z'; b++) if (n.cls[b] != n.cls[b - 32]) case_closed = false;
-      if (cnt <= 4 || (case_closed && folded.count() <= 4)) {
+      if (cnt <= 10 || (case_closed && folded.count() <= 10)) {
         r.exact = true;
         for (int b = 0; b < 256; b++) {
           if (!n.cls[b]) continue;
@@ -861,6 +856,183 @@ Lit clip(const Lit &l) {
     if (s < best_score) { best_score = s; best = o; }
   }
   return {l.bytes.substr(best, HG_FACTOR_MAX), l.cmask.substr(best, HG_FACTOR_MAX)};
+}
+
+// Occurrence counts of dword-aligned windows in a text sample (hgc_tune).
+struct SampleStats {
+  std::unordered_map<uint32_t, uint32_t> c4;  // folded dword
+  std::unordered_map<uint64_t, uint32_t> c6;  // folded dword | folded first two bytes of the next dword << 32
+  size_t dwords = 0;
+};
+
+// (Re)build windows, bucket index, LDS filter slots and neighbour conditions from db.factors.
+int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
+  db.windows.clear();
+  std::vector<std::pair<uint32_t, HgWindow>> keyed;
+  std::vector<uint32_t> next16_of;  // per keyed entry: hg_next16 of the two bytes after the window, 0 if unknown
+  const uint32_t fold = db.fold_mask;
+  for (uint32_t fi = 0; fi < db.nreal_factors; fi++) {
+    const HgFactor &fct = db.factors[fi];
+    Lit l{std::string(reinterpret_cast<const char *>(fct.lit), fct.len), std::string(reinterpret_cast<const char *>(fct.cmask), fct.len)};
+    for (uint32_t res = 0; res < 4; res++) {
+      // One 3-byte window per residue mod 4.  The stream kernel compares the window in its hot path and the 11-byte
+      // neighbourhood [o-4, o+7) in the second level.
+      // With sample statistics: take the offset whose window dword is rarest in the sample.  Without:
+      // the offset whose known bytes are the most selective by a static byte-frequency table.
+      int best = -1;
+      long best_cost = 0;
+      int best_sel = -1;
+      for (uint32_t o = res; o + HG_WINDOW_BYTES <= fct.len; o += 4) {
+        uint32_t v = 0, nx = 0;
+        std::memcpy(&v, fct.lit + o, HG_WINDOW_BYTES);
+        v = (v | fold) & HG_WINDOW_MASK;
+        const bool has_next = o + 6 <= fct.len;
+        if (has_next) nx = (static_cast<uint32_t>(fct.lit[o + 4]) | (static_cast<uint32_t>(fct.lit[o + 5]) << 8) | fold) & 0xFFFFu;
+        long cost = 0;
+        if (stats) {  // the hot path compares the window dword alone: its frequency in the sample is what costs
+          auto it = stats->c4.find(v);
+          cost = it == stats->c4.end() ? 0 : it->second;
+          (void)nx;
+          (void)has_next;
+        }
+        int sel = 0;
+        for (int j = static_cast<int>(o); j < static_cast<int>(o + HG_WINDOW_BYTES); j++) sel += 11 - byte_commonness(static_cast<unsigned char>(l.bytes[j]));
+        for (int j = std::max(static_cast<int>(o) - 4, 0); j < std::min<int>(o + 7, fct.len); j++)
+          sel += (11 - byte_commonness(static_cast<unsigned char>(l.bytes[j]))) / 4;
+        if (best < 0 || cost < best_cost || (cost == best_cost && sel > best_sel)) { best = static_cast<int>(o); best_cost = cost; best_sel = sel; }
+      }
+      if (best < 0) continue;  // cannot happen for len >= HG_FAST_MIN_FACTOR
+      uint32_t v = 0;
+      std::memcpy(&v, fct.lit + best, HG_WINDOW_BYTES);
+      v = (v | fold) & HG_WINDOW_MASK;  // case-insensitive positions hold lower-case letters already; folding maps both cases onto them
+      uint32_t n16 = 0;  // (reserved: hash of the two bytes after the window)
+      keyed.push_back({hg_hash_window(v), HgWindow{v, (fi << 8) | static_cast<uint32_t>(best)}});
+      next16_of.push_back(n16);
+    }
+  }
+  {  // sort by bucket, carrying next16 along
+    std::vector<size_t> order(keyed.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return keyed[x].first < keyed[y].first; });
+    std::vector<std::pair<uint32_t, HgWindow>> k2;
+    std::vector<uint32_t> n2;
+    for (size_t i : order) { k2.push_back(keyed[i]); n2.push_back(next16_of[i]); }
+    keyed.swap(k2);
+    next16_of.swap(n2);
+  }
+  db.bucket_off.assign((1u << HG_HASH_BITS) + 1, 0);
+  for (auto &kw : keyed) {
+    db.bucket_off[kw.first + 1]++;
+    db.windows.push_back(kw.second);
+  }
+  for (size_t i = 1; i < db.bucket_off.size(); i++) db.bucket_off[i] += db.bucket_off[i - 1];
+  if (db.windows.empty()) db.windows.push_back(HgWindow{0, 0});  // keep device arrays non-empty
+
+  // LDS filter: cuckoo placement of the hash of each distinct window value.  Every value owns exactly one of its
+  // two slots, so a lookup that reads both slots can never miss it.
+  std::vector<uint32_t> values;
+  for (auto &kw : keyed) values.push_back(kw.second.value);
+  std::sort(values.begin(), values.end());
+  values.erase(std::unique(values.begin(), values.end()), values.end());
+  bool placed = false;
+  for (uint32_t attempt = 0; attempt < (HG_FILTER_MAX_LOG2 - HG_FILTER_MIN_LOG2 + 1) * HG_SLOT_WEIGHT_NCHOICES && !placed; attempt++) {
+    // smallest table first; for each size every weight pair
+    const uint32_t k = HG_FILTER_MIN_LOG2 + attempt / HG_SLOT_WEIGHT_NCHOICES;
+    const uint32_t wa = HG_SLOT_WEIGHT_CHOICES[attempt % HG_SLOT_WEIGHT_NCHOICES][0], wb = HG_SLOT_WEIGHT_CHOICES[attempt % HG_SLOT_WEIGHT_NCHOICES][1];
+    if (values.size() * 100 > (size_t(1) << k) * (k == HG_FILTER_MAX_LOG2 ? 49 : 45)) continue;  // keep the load under 45 %
+    const uint32_t byte_mask = ((1u << k) - 1u) << 2;
+    struct Entry { uint32_t sa, sb, fp; };
+    std::vector<Entry> entries;
+    {
+      std::vector<std::array<uint32_t, 3>> keys;  // values with the same slot pair and fingerprint are one entry
+      for (uint32_t v : values) {
+        uint32_t sa = hg_slot(v, wa, byte_mask) >> 2, sb = hg_slot(v, wb, byte_mask) >> 2;
+        keys.push_back({std::min(sa, sb), std::max(sa, sb), hg_hash_window(v)});
+      }
+      std::sort(keys.begin(), keys.end());
+      keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+      for (auto &key : keys) entries.push_back({key[0], key[1], key[2]});
+    }
+    std::vector<int32_t> owner(size_t(1) << k, -1);  // entry index owning the slot
+    uint64_t rng = 0x9E3779B97F4A7C15ull;
+    placed = true;
+    for (size_t e = 0; e < entries.size() && placed; e++) {
+      int32_t cur = static_cast<int32_t>(e);
+      bool ok = false;
+      for (int kick = 0; kick < 4000; kick++) {
+        uint32_t sa = entries[cur].sa, sb = entries[cur].sb;
+        if (owner[sa] < 0) { owner[sa] = cur; ok = true; break; }
+        if (owner[sb] < 0) { owner[sb] = cur; ok = true; break; }
+        rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+        uint32_t slot = ((rng >> 33) & 1) ? sa : sb;
+        std::swap(cur, owner[slot]);
+      }
+      if (!ok) placed = false;
+    }
+    if (!placed) continue;
+    db.filter.assign(size_t(1) << k, HG_FILTER_EMPTY);
+    db.ext.assign(size_t(1) << k, HgFilterExt{0, 0, 0, 0});
+    std::vector<bool> seen(size_t(1) << k, false);
+    std::vector<uint32_t> slot_n16(size_t(1) << k, 0);
+    db.filter_log2 = k;
+    db.weights_a = wa;
+    db.weights_b = wb;
+    // per owning slot: next-two-bytes hash (kept only if all its windows agree) and the neighbour-dword conditions
+    // (byte-wise agreement of all its windows)
+    auto merge = [](uint32_t &val, uint32_t &mask, uint32_t v2, uint32_t m2) {
+      uint32_t keep = 0;
+      for (int b = 0; b < 4; b++) {
+        uint32_t bm = 0xFFu << (8 * b);
+        if ((mask & bm) && (m2 & bm) && ((val ^ v2) & bm) == 0) keep |= bm;
+      }
+      mask = keep;
+      val &= keep;
+    };
+    for (size_t wi = 0; wi < keyed.size(); wi++) {
+      const HgWindow &w = keyed[wi].second;
+      const HgFactor &f = db.factors[w.factor_off >> 8];
+      const int o = static_cast<int>(w.factor_off & 0xff);
+      uint32_t pv = 0, pm = 0, nv = 0, nm = 0;
+      for (int b = 0; b < 4; b++) {
+        int jp = o - 4 + b, jn = o + static_cast<int>(HG_WINDOW_BYTES) + b;
+        if (jp >= 0) { pv |= static_cast<uint32_t>(f.lit[jp]) << (8 * b); pm |= 0xFFu << (8 * b); }
+        if (jn < static_cast<int>(f.len)) { nv |= static_cast<uint32_t>(f.lit[jn]) << (8 * b); nm |= 0xFFu << (8 * b); }
+      }
+      pv = (pv | fold) & pm;
+      nv = (nv | fold) & nm;
+      if (!fold) {  // case-insensitive letters cannot be compared exactly without folding: drop them
+        for (int b = 0; b < 4; b++) {
+          int jp = o - 4 + b, jn = o + static_cast<int>(HG_WINDOW_BYTES) + b;
+          if (jp >= 0 && f.cmask[jp] != 0xFF) { pm &= ~(0xFFu << (8 * b)); pv &= pm; }
+          if (jn < static_cast<int>(f.len) && f.cmask[jn] != 0xFF) { nm &= ~(0xFFu << (8 * b)); nv &= nm; }
+        }
+      }
+      uint32_t sa = hg_slot(w.value, wa, byte_mask) >> 2, sb = hg_slot(w.value, wb, byte_mask) >> 2;
+      uint32_t fp = hg_hash_window(w.value);
+      for (uint32_t sl : {sa, sb}) {  // the entry for (sa, sb, fp) sits in exactly one of the two slots
+        if (owner[sl] < 0) continue;
+        const Entry &e = entries[owner[sl]];
+        if (e.fp != fp || e.sa != std::min(sa, sb) || e.sb != std::max(sa, sb)) continue;
+        HgFilterExt &x = db.ext[sl];
+        if (!seen[sl]) {
+          x = HgFilterExt{pv, pm, nv, nm};
+          slot_n16[sl] = next16_of[wi];
+          seen[sl] = true;
+        } else {
+          merge(x.pv, x.pm, pv, pm);
+          merge(x.nv, x.nm, nv, nm);
+          if (slot_n16[sl] != next16_of[wi]) slot_n16[sl] = 0;
+        }
+      }
+    }
+    for (size_t sl = 0; sl < owner.size(); sl++)
+      if (owner[sl] >= 0) db.filter[sl] = entries[owner[sl]].fp;
+  }
+  if (!placed) {
+    if (err) *err = "too many distinct literal windows for the LDS filter";
+    return -4;
+  }
+  return 0;
 }
 
 }  // namespace
@@ -1002,8 +1174,7 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
     return -2;
   }
 
-  // factors + windows (needs the final fold mask)
-  std::vector<std::pair<uint32_t, HgWindow>> keyed;
+  // factors (needs the final fold mask); windows and filter tables are built from them
   for (unsigned i = 0; i < n; i++) {
     for (auto &l : covers[i].lits) {
       HgFactor fct{};
@@ -1011,141 +1182,36 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
       fct.len = static_cast<uint32_t>(l.bytes.size());
       std::memcpy(fct.lit, l.bytes.data(), fct.len);
       std::memcpy(fct.cmask, l.cmask.data(), fct.len);
-      uint32_t fi = static_cast<uint32_t>(db->factors.size());
       db->factors.push_back(fct);
-      for (uint32_t res = 0; res < 4; res++) {
-        // the stream kernel checks the window dword and, masked, the dwords before and after it: pick the offset
-        // whose 12-byte neighbourhood [o-4, o+8) covers the most selective bytes of the literal
-        int best = -1, best_sel = -1, best_win = INT32_MAX;
-        for (uint32_t o = res; o + 4 <= fct.len; o += 4) {
-          int sel = 0;
-          int lo = static_cast<int>(o) - 4, hi = static_cast<int>(o) + 8;
-          for (int j = std::max(lo, 0); j < std::min<int>(hi, static_cast<int>(fct.len)); j++)
-            sel += 11 - byte_commonness(static_cast<unsigned char>(l.bytes[j]));
-          int win = window_score(l, o);
-          if (sel > best_sel || (sel == best_sel && win < best_win)) { best_sel = sel; best_win = win; best = static_cast<int>(o); }
-        }
-        if (best < 0) continue;  // cannot happen for len >= 7
-        uint32_t v;
-        std::memcpy(&v, fct.lit + best, 4);
-        // case-insensitive positions hold lower-case letters already; folding maps both cases onto them
-        v |= db->fold_mask;
-        HgWindow w{v, (fi << 8) | static_cast<uint32_t>(best)};
-        keyed.push_back({hg_hash_window(v), w});
-      }
     }
   }
-  std::stable_sort(keyed.begin(), keyed.end(), [](auto &a, auto &b) { return a.first < b.first; });
-  db->bucket_off.assign((1u << HG_HASH_BITS) + 1, 0);
-  for (auto &kw : keyed) {
-    db->bucket_off[kw.first + 1]++;
-    db->windows.push_back(kw.second);
+  db->nreal_factors = static_cast<uint32_t>(db->factors.size());
+  if (db->factors.empty()) db->factors.push_back(HgFactor{});  // keep device arrays non-empty
+  if (build_filter(*db, nullptr, err) != 0) {
+    if (bad_index) *bad_index = -1;
+    return -4;
   }
-  for (size_t i = 1; i < db->bucket_off.size(); i++) db->bucket_off[i] += db->bucket_off[i - 1];
-  // LDS fingerprint filter: cuckoo placement of the hash of each distinct window value.  Every value
-  // owns exactly one of its two slots, so a lookup that reads both slots can never miss it.
-  {
-    std::vector<uint32_t> values;
-    for (auto &kw : keyed) values.push_back(kw.second.value);
-    std::sort(values.begin(), values.end());
-    values.erase(std::unique(values.begin(), values.end()), values.end());
-    bool placed = false;
-    for (uint32_t attempt = 0; attempt < (HG_FILTER_MAX_LOG2 - HG_FILTER_MIN_LOG2 + 1) * HG_SLOT_WEIGHT_NCHOICES && !placed; attempt++) {
-      // smallest table first; for each size every weight pair
-      const uint32_t k = HG_FILTER_MIN_LOG2 + attempt / HG_SLOT_WEIGHT_NCHOICES;
-      const uint32_t wa = HG_SLOT_WEIGHT_CHOICES[attempt % HG_SLOT_WEIGHT_NCHOICES][0], wb = HG_SLOT_WEIGHT_CHOICES[attempt % HG_SLOT_WEIGHT_NCHOICES][1];
-      if (values.size() * 100 > (size_t(1) << k) * (k == HG_FILTER_MAX_LOG2 ? 49 : 45)) continue;  // keep the load under 45 %
-      const uint32_t byte_mask = ((1u << k) - 1u) << 2;
-      struct Entry { uint32_t sa, sb, fp; };
-      std::vector<Entry> entries;
-      {
-        std::vector<std::array<uint32_t, 3>> keys;  // values with the same slot pair and fingerprint are one entry
-        for (uint32_t v : values) {
-          uint32_t sa = hg_slot(v, wa, byte_mask) >> 2, sb = hg_slot(v, wb, byte_mask) >> 2;
-          keys.push_back({std::min(sa, sb), std::max(sa, sb), hg_hash_window(v)});
-        }
-        std::sort(keys.begin(), keys.end());
-        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
-        for (auto &key : keys) entries.push_back({key[0], key[1], key[2]});
-      }
-      std::vector<int32_t> owner(size_t(1) << k, -1);  // entry index owning the slot
-      uint64_t rng = 0x9E3779B97F4A7C15ull;
-      placed = true;
-      for (size_t e = 0; e < entries.size() && placed; e++) {
-        int32_t cur = static_cast<int32_t>(e);
-        bool ok = false;
-        for (int kick = 0; kick < 4000; kick++) {
-          uint32_t sa = entries[cur].sa, sb = entries[cur].sb;
-          if (owner[sa] < 0) { owner[sa] = cur; ok = true; break; }
-          if (owner[sb] < 0) { owner[sb] = cur; ok = true; break; }
-          rng = rng * 6364136223846793005ull + 1442695040888963407ull;
-          uint32_t slot = ((rng >> 33) & 1) ? sa : sb;
-          std::swap(cur, owner[slot]);
-        }
-        if (!ok) placed = false;
-      }
-      if (placed) {
-        db->filter.assign(size_t(1) << k, HG_FILTER_EMPTY);
-        db->ext.assign(size_t(1) << k, HgFilterExt{0, 0, 0, 0});
-        std::vector<bool> seen(size_t(1) << k, false);
-        for (size_t sl = 0; sl < owner.size(); sl++)
-          if (owner[sl] >= 0) db->filter[sl] = entries[owner[sl]].fp;
-        db->filter_log2 = k;
-        db->weights_a = wa;
-        db->weights_b = wb;
-        // neighbour-dword conditions of every window, merged (byte-wise agreement) per owning slot
-        auto merge = [](uint32_t &val, uint32_t &mask, uint32_t v2, uint32_t m2) {
-          uint32_t keep = 0;
-          for (int b = 0; b < 4; b++) {
-            uint32_t bm = 0xFFu << (8 * b);
-            if ((mask & bm) && (m2 & bm) && ((val ^ v2) & bm) == 0) keep |= bm;
-          }
-          mask = keep;
-          val &= keep;
-        };
-        for (auto &kw : keyed) {
-          const HgWindow &w = kw.second;
-          const HgFactor &f = db->factors[w.factor_off >> 8];
-          const int o = static_cast<int>(w.factor_off & 0xff);
-          uint32_t pv = 0, pm = 0, nv = 0, nm = 0;
-          for (int b = 0; b < 4; b++) {
-            int jp = o - 4 + b, jn = o + 4 + b;
-            if (jp >= 0) { pv |= static_cast<uint32_t>(f.lit[jp]) << (8 * b); pm |= 0xFFu << (8 * b); }
-            if (jn < static_cast<int>(f.len)) { nv |= static_cast<uint32_t>(f.lit[jn]) << (8 * b); nm |= 0xFFu << (8 * b); }
-          }
-          pv = (pv | db->fold_mask) & pm;
-          nv = (nv | db->fold_mask) & nm;
-          if (!db->fold_mask) {  // case-insensitive letters cannot be compared exactly without folding: drop them
-            for (int b = 0; b < 4; b++) {
-              int jp = o - 4 + b, jn = o + 4 + b;
-              if (jp >= 0 && f.cmask[jp] != 0xFF) { pm &= ~(0xFFu << (8 * b)); pv &= pm; }
-              if (jn < static_cast<int>(f.len) && f.cmask[jn] != 0xFF) { nm &= ~(0xFFu << (8 * b)); nv &= nm; }
-            }
-          }
-          uint32_t sa = hg_slot(w.value, wa, byte_mask) >> 2, sb = hg_slot(w.value, wb, byte_mask) >> 2;
-          uint32_t fp = hg_hash_window(w.value);
-          // the entry for (sa, sb, fp) sits in exactly one of the two slots
-          for (uint32_t sl : {sa, sb}) {
-            if (owner[sl] < 0) continue;
-            const Entry &e = entries[owner[sl]];
-            if (e.fp != fp || e.sa != std::min(sa, sb) || e.sb != std::max(sa, sb)) continue;
-            HgFilterExt &x = db->ext[sl];
-            if (!seen[sl]) { x = HgFilterExt{pv, pm, nv, nm}; seen[sl] = true; }
-            else { merge(x.pv, x.pm, pv, pm); merge(x.nv, x.nm, nv, nm); }
-          }
-        }
-      }
-    }
-    if (!placed) {
-      if (err) *err = "too many distinct literal windows for the LDS filter";
-      if (bad_index) *bad_index = -1;
-      return -4;
-    }
-  }
-  if (db->windows.empty()) db->windows.push_back(HgWindow{0, 0});  // keep device arrays non-empty
-  if (db->factors.empty()) db->factors.push_back(HgFactor{});
   *out = db.release();
   return 0;
+}
+
+int hgc_tune(HgDb *db, const uint8_t *sample, size_t nbytes, std::string *err) {
+  if (!db || (!sample && nbytes)) return -1;
+  SampleStats st;
+  const uint32_t fold = db->fold_mask;
+  for (size_t p = 0; p + 4 <= nbytes; p += 4) {
+    uint32_t w, nx = 0;
+    std::memcpy(&w, sample + p, 4);
+    if (p + 8 <= nbytes) std::memcpy(&nx, sample + p + 4, 4);
+    w = (w | fold) & HG_WINDOW_MASK;
+    nx |= fold;
+    st.c4[w]++;
+    st.c6[static_cast<uint64_t>(w) | (static_cast<uint64_t>(nx & 0xFFFFu) << 32)]++;
+  }
+  st.dwords = nbytes / 4;
+  int rc = build_filter(*db, &st, err);
+  if (rc == 0) db->tuned = true;
+  return rc;
 }
 
 void hgc_free(HgDb *db) { delete db; }

@@ -12,6 +12,7 @@ struct HgDb {
   std::vector<HgPattern> patterns;
   std::vector<uint32_t> pool;        // all automaton tables
   std::vector<HgFactor> factors;     // required literals of tier-0 patterns
+  uint32_t nreal_factors = 0;
   std::vector<HgWindow> windows;     // grouped by bucket
   std::vector<uint32_t> bucket_off;  // (1 << HG_HASH_BITS) + 1 offsets into windows
   std::vector<uint32_t> filter;      // 1 << filter_log2 slots holding hash C of the owning window (staged in LDS by the stream kernel)
@@ -23,9 +24,14 @@ struct HgDb {
   uint32_t max_nw = 1;
   uint32_t n_confirm_mode[HG_CONFIRM_MODES] = {0, 0, 0, 0};  // tier-0 patterns by confirm routine (hg_confirm_mode)
   std::vector<std::string> exprs;
+  bool tuned = false;
 };
 
 // Returns 0 on success.  On failure returns non-zero, sets *err and *bad_index (expression index or -1).
+// Re-select the literal windows using byte statistics of a text sample (any prefix of the text to be scanned) and
+// rebuild the filter tables; never changes results, only how often the slow stages run.  Returns 0 on success.
+int hgc_tune(HgDb *db, const uint8_t *sample, size_t nbytes, std::string *err);
+
 int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned *ids, unsigned n, HgDb **out,
                std::string *err, int *bad_index);
 void hgc_free(HgDb *db);

@@ -23,7 +23,7 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *text, uint
 // hg_verify_window with dword compares.  The text buffer is readable up to nbytes rounded up to 16.
 template <typename Emit>
 __device__ __forceinline__ void verify_window(const HgDbView &db, const uint8_t *text, uint64_t nbytes, uint64_t pos, uint32_t w, Emit &&emit) {
-  const uint32_t folded = w | db.fold_mask;
+  const uint32_t folded = (w | db.fold_mask) & HG_WINDOW_MASK;
   const uint32_t h = hg_hash_window(folded);
   for (uint32_t j = db.bucket_off[h], e = db.bucket_off[h + 1]; j < e; j++) {
     const HgWindow win = db.windows[j];

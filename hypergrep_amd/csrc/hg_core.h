@@ -95,7 +95,7 @@ HG_HD uint32_t hg_prev_ctx(uint32_t c) { return c == '\n' ? HG_PC_NL : (hg_is_wo
 template <typename Emit>
 HG_HD void hg_verify_window(const HgDbView &db, const uint8_t *text, uint64_t nbytes, uint64_t pos, uint32_t w,
                             Emit &&emit) {
-  uint32_t folded = w | db.fold_mask;
+  uint32_t folded = (w | db.fold_mask) & HG_WINDOW_MASK;
   uint32_t h = hg_hash_window(folded);
   for (uint32_t j = db.bucket_off[h], e = db.bucket_off[h + 1]; j < e; j++) {
     HgWindow win = db.windows[j];

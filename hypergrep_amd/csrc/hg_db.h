@@ -26,7 +26,11 @@ constexpr uint32_t HG_TT_ALL = (1u << 20) - 1;
 constexpr uint32_t HG_MAX_NODES = 1024;  // per pattern (32 state words)
 constexpr uint32_t HG_MAX_W = HG_MAX_NODES / 32;
 constexpr uint32_t HG_FACTOR_MAX = 32;   // bytes of a required literal kept for the in-stream verify
-constexpr uint32_t HG_FAST_MIN_FACTOR = 7;  // 4-byte window on every residue mod 4 needs length >= 7
+// A window = the low HG_WINDOW_BYTES bytes of a dword-aligned text dword.  4 and 3 are supported; measured on the
+// round-1 workload a 3-byte window admits 6-byte literals to the fast tier but is hit 1.5x more often by filler text.
+constexpr uint32_t HG_WINDOW_BYTES = 4;
+constexpr uint32_t HG_WINDOW_MASK = HG_WINDOW_BYTES == 4 ? 0xFFFFFFFFu : 0x00FFFFFFu;
+constexpr uint32_t HG_FAST_MIN_FACTOR = HG_WINDOW_BYTES + 3;  // a window on every residue mod 4
 constexpr uint32_t HG_HASH_BITS = 18;       // v_dot4_u32_u8 of four bytes with weights < 256 fits 18 bits
 // Three byte-weighted sums of the (case-folded) window dword, one v_dot4_u32_u8 each:
 //   hash C  -> bucket index of the window table in HBM, and (low 16 bits) the fingerprint
@@ -34,14 +38,16 @@ constexpr uint32_t HG_HASH_BITS = 18;       // v_dot4_u32_u8 of four bytes with 
 //   candidate slots of the window in the LDS filter (cuckoo placement: every window sits in exactly one of them).
 // A slot holds the window's full hash C (18 bits) in a dword: sub-dword LDS reads (ds_read_u16) measured ~8x
 // slower than ds_read_b32 on gfx950 for this random-access pattern.
-constexpr uint32_t HG_HASH_WEIGHTS = 0xfbf1efe9u;    // C: 233, 239, 241, 251
+// (with 3-byte windows the weight of the dword's top byte is zero in all three sums: that byte is not part of the window)
+constexpr uint32_t HG_TOP_WEIGHT_MASK = HG_WINDOW_BYTES == 4 ? 0xFFFFFFFFu : 0x00FFFFFFu;
+constexpr uint32_t HG_HASH_WEIGHTS = 0xfbf1efe9u & HG_TOP_WEIGHT_MASK;  // C: 233, 239, 241, 251
 // A / B weight pairs the compiler tries in turn until the cuckoo placement succeeds (bytes are multiples of 4
 // and deliberately not in arithmetic progression, so that no small byte difference cancels in both sums).
 constexpr uint32_t HG_SLOT_WEIGHT_CHOICES[][2] = {
-    {0x2cec94fcu, 0xbc34f474u},  // A: 252,148,236,44   B: 116,244,52,188
-    {0x74d43cb4u, 0xe40c9c5cu},  // A: 180,60,212,116   B: 92,156,12,228
-    {0xa41cf86cu, 0x54c4247cu},  // A: 108,248,28,164   B: 124,36,196,84
-    {0xdc4484f4u, 0x1cac6cccu},  // A: 244,132,68,220   B: 204,108,172,28
+    {0x2cec94fcu & HG_TOP_WEIGHT_MASK, 0xbc34f474u & HG_TOP_WEIGHT_MASK},  // A: 252,148,236,44   B: 116,244,52,188
+    {0x74d43cb4u & HG_TOP_WEIGHT_MASK, 0xe40c9c5cu & HG_TOP_WEIGHT_MASK},  // A: 180,60,212,116   B: 92,156,12,228
+    {0xa41cf86cu & HG_TOP_WEIGHT_MASK, 0x54c4247cu & HG_TOP_WEIGHT_MASK},  // A: 108,248,28,164   B: 124,36,196,84
+    {0xdc4484f4u & HG_TOP_WEIGHT_MASK, 0x1cac6cccu & HG_TOP_WEIGHT_MASK},  // A: 244,132,68,220   B: 204,108,172,28
 };
 constexpr uint32_t HG_SLOT_WEIGHT_NCHOICES = 4;
 constexpr uint32_t HG_FILTER_MIN_LOG2 = 11, HG_FILTER_MAX_LOG2 = 15;  // 4-byte slots: 8 KiB .. 128 KiB of LDS
@@ -79,7 +85,7 @@ struct HgFactor {
 };
 static_assert(sizeof(HgFactor) == 80, "HgFactor layout");
 
-// One 4-byte window of a factor, placed at literal offset `off`; keyed by the (folded) dword value.
+// One window (HG_WINDOW_BYTES bytes) of a factor, placed at literal offset `off`; keyed by the folded, masked dword value.
 struct HgWindow {
   uint32_t value;
   uint32_t factor_off;  // factor index << 8 | off
@@ -99,8 +105,8 @@ HG_HD uint32_t hg_slot(uint32_t folded, uint32_t weights, uint32_t byte_mask) { 
 // Second-level check of a filter slot: what the dwords just before / after the window must look like
 // (folded, byte-masked) for any of the slot's windows to be part of its literal.  Conservative union.
 struct HgFilterExt {
-  uint32_t pv, pm;  // previous dword: (prev | fold) & pm == pv
-  uint32_t nv, nm;  // next dword
+  uint32_t pv, pm;  // the 4 bytes before the window: (prev | fold) & pm == pv
+  uint32_t nv, nm;  // the 4 bytes after the window (with 3-byte windows they start with the top byte of the window's own dword)
 };
 HG_HD bool hg_ext_pass(const HgFilterExt &e, uint32_t prev_folded, uint32_t next_folded) {
   return (((prev_folded ^ e.pv) & e.pm) | ((next_folded ^ e.nv) & e.nm)) == 0;

@@ -87,59 +87,59 @@ __device__ __noinline__ void append_matches(HgCand *__restrict__ seg, uint32_t s
 template <int LOG2>
 struct Probe {
   static constexpr uint32_t BYTE_MASK = ((1u << LOG2) - 1u) << 2;
-  // ANY_ONLY: non-zero iff any of the four windows matched (hot path); else bit k set iff window k matched
+  // First level for the lane's four dwords: a slot matches if it holds the window's hash C.
+  // ANY_ONLY: non-zero iff any of the four windows matched (hot path); else bit k set iff window k matched.
   template <bool ANY_ONLY>
   __device__ __forceinline__ static uint32_t probe4(const uint32_t *filter, uint32_t fold, uint32_t wa, uint32_t wb, uint4 v) {
     const uint32_t f0 = v.x | fold, f1 = v.y | fold, f2 = v.z | fold, f3 = v.w | fold;
-    // the three hashes of the four windows first (independent v_dot4), then the eight LDS reads
-    const uint32_t a0 = hg_dot4(f0, wa), a1 = hg_dot4(f1, wa);
-    const uint32_t a2 = hg_dot4(f2, wa), a3 = hg_dot4(f3, wa);
-    const uint32_t b0 = hg_dot4(f0, wb), b1 = hg_dot4(f1, wb);
-    const uint32_t b2 = hg_dot4(f2, wb), b3 = hg_dot4(f3, wb);
+    // the hashes of the four windows first (independent v_dot4), then the eight LDS reads
+    const uint32_t a0 = hg_dot4(f0, wa), a1 = hg_dot4(f1, wa), a2 = hg_dot4(f2, wa), a3 = hg_dot4(f3, wa);
+    const uint32_t b0 = hg_dot4(f0, wb), b1 = hg_dot4(f1, wb), b2 = hg_dot4(f2, wb), b3 = hg_dot4(f3, wb);
     const uint32_t c0 = hg_dot4(f0, HG_HASH_WEIGHTS), c1 = hg_dot4(f1, HG_HASH_WEIGHTS);
     const uint32_t c2 = hg_dot4(f2, HG_HASH_WEIGHTS), c3 = hg_dot4(f3, HG_HASH_WEIGHTS);
     const uint8_t *base = reinterpret_cast<const uint8_t *>(filter);
     auto at = [&](uint32_t h) { return *reinterpret_cast<const uint32_t *>(base + (h & BYTE_MASK)); };
     const uint32_t ta0 = at(a0), tb0 = at(b0), ta1 = at(a1), tb1 = at(b1), ta2 = at(a2), tb2 = at(b2), ta3 = at(a3), tb3 = at(b3);
-    if (ANY_ONLY) return (ta0 == c0 || tb0 == c0 || ta1 == c1 || tb1 == c1 || ta2 == c2 || tb2 == c2 || ta3 == c3 || tb3 == c3) ? 1u : 0u;
-    uint32_t hits = (ta0 == c0 || tb0 == c0) ? 1u : 0u;
-    hits |= (ta1 == c1 || tb1 == c1) ? 2u : 0u;
-    hits |= (ta2 == c2 || tb2 == c2) ? 4u : 0u;
-    hits |= (ta3 == c3 || tb3 == c3) ? 8u : 0u;
-    return hits;
+    const bool m0 = ta0 == c0 || tb0 == c0, m1 = ta1 == c1 || tb1 == c1, m2 = ta2 == c2 || tb2 == c2, m3 = ta3 == c3 || tb3 == c3;
+    if (ANY_ONLY) return (m0 || m1 || m2 || m3) ? 1u : 0u;
+    return (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u) | (m3 ? 8u : 0u);
   }
 };
 
-// Second level, entered when some lane's fingerprint matched: the dwords before and after the window must
-// agree (byte-masked) with what the slot's literals have there.  Returns bit k set iff window k survives.
+// Second level, entered when some lane's first level matched: the dwords before and after the window must
+// agree (byte-masked) with what the slot's literals have there.  `hits`: bit k = window k passed the first level.
+// Returns bit k set iff window k survives.
 template <int LOG2>
-__device__ __forceinline__ uint32_t level2_filter(const uint32_t *filter, const HgFilterExt *ext, uint32_t fold, uint32_t wa, uint32_t wb, uint4 v, uint32_t lane) {
+__device__ __forceinline__ uint32_t level2_filter(const uint32_t *filter, const HgFilterExt *ext, uint32_t fold, uint32_t wa, uint32_t wb, uint4 v,
+                                                  uint32_t left, uint32_t right, uint32_t lane, uint32_t hits) {
   constexpr uint32_t BYTE_MASK = ((1u << LOG2) - 1u) << 2;
   const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-  // neighbours across the lane edge come from the adjacent lanes; the first / last lane of the wave has none
-  const uint32_t left = __shfl_up(v.w, 1, 64), right = __shfl_down(v.x, 1, 64);
   const uint8_t *base = reinterpret_cast<const uint8_t *>(filter);
   uint32_t out = 0;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const uint32_t f = w[k] | fold;
-    const uint32_t sa = hg_dot4(f, wa) & BYTE_MASK, sb = hg_dot4(f, wb) & BYTE_MASK;
-    const uint32_t fp = hg_dot4(f, HG_HASH_WEIGHTS);
-    const bool ha = *reinterpret_cast<const uint32_t *>(base + sa) == fp, hb = *reinterpret_cast<const uint32_t *>(base + sb) == fp;
-    if (ha || hb) {
-      const uint32_t prev = (k == 0 ? left : w[k - 1]) | fold, next = (k == 3 ? right : w[k + 1]) | fold;
+    if ((hits >> k) & 1u) {
+      const uint32_t f = w[k] | fold;
+      const uint32_t sa = hg_dot4(f, wa) & BYTE_MASK, sb = hg_dot4(f, wb) & BYTE_MASK;
+      const uint32_t fp = hg_dot4(f, HG_HASH_WEIGHTS);
+      const bool ha = *reinterpret_cast<const uint32_t *>(base + sa) == fp;
+      const bool hb = *reinterpret_cast<const uint32_t *>(base + sb) == fp;
+      // the 4 bytes before the window, and the 4 bytes after it (top byte of its own dword + 3 of the next)
+      const uint32_t prev = (k == 0 ? left : w[k - 1]) | fold;
+      const uint32_t next_dword = k == 3 ? right : w[k + 1];
+      const uint32_t next = (HG_WINDOW_BYTES == 4 ? next_dword : ((w[k] >> 24) | (next_dword << 8))) | fold;
       const bool no_prev = k == 0 && lane == 0, no_next = k == 3 && lane == 63;
       bool ok = false;
       if (ha) {
         HgFilterExt e = ext[sa >> 2];
         if (no_prev) e.pm = 0, e.pv = 0;
-        if (no_next) e.nm = 0, e.nv = 0;
+        if (no_next) e.nm &= (HG_WINDOW_BYTES == 4 ? 0u : 0xFFu), e.nv &= (HG_WINDOW_BYTES == 4 ? 0u : 0xFFu);
         ok = hg_ext_pass(e, prev, next);
       }
       if (hb && !ok) {
         HgFilterExt e = ext[sb >> 2];
         if (no_prev) e.pm = 0, e.pv = 0;
-        if (no_next) e.nm = 0, e.nv = 0;
+        if (no_next) e.nm &= (HG_WINDOW_BYTES == 4 ? 0u : 0xFFu), e.nv &= (HG_WINDOW_BYTES == 4 ? 0u : 0xFFu);
         ok = hg_ext_pass(e, prev, next);
       }
       if (ok) out |= 1u << k;
@@ -202,7 +202,9 @@ __device__ __forceinline__ void stream_tile(const uint4 *__restrict__ text16, ui
       last_lane = 63u - __builtin_clzll(nlm);
     }
     if (__ballot(any)) {
-      const uint32_t hits = level2_filter<LOG2>(filter, ext, fold, wa, wb, cur, lane);
+      const uint32_t l1 = Probe<LOG2>::template probe4<false>(filter, fold, wa, wb, cur);
+      const uint32_t left = __shfl_up(cur.w, 1, 64), right = __shfl_down(cur.x, 1, 64);
+      const uint32_t hits = level2_filter<LOG2>(filter, ext, fold, wa, wb, cur, left, right, lane, l1);
       if (__ballot(hits != 0))
         append_matches(seg, seg_cap, lds_count, (chunk0 + static_cast<uint64_t>(it) * 64u) << 4, lane, cur, tot, hits);
     }

@@ -52,6 +52,7 @@ def lib() -> ctypes.CDLL:
         l.hg_db_compile.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint),
                                     ctypes.c_uint, ctypes.POINTER(ctypes.c_void_p), ctypes.c_char_p, ctypes.c_size_t]
         l.hg_db_release.argtypes = [ctypes.c_void_p]
+        l.hg_db_tune.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
         l.hg_db_info.argtypes = [ctypes.c_void_p, ctypes.POINTER(HgDbInfo)]
         l.hg_scanner_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_char_p, ctypes.c_size_t]
         l.hg_scanner_destroy.argtypes = [ctypes.c_void_p]
@@ -85,6 +86,11 @@ class Database:
         rc = lib().hg_db_compile(pa, fa, ia, len(pa), ctypes.byref(self._h), err, 512)
         if rc != 0:
             raise CompileError(err.value.decode(errors="replace"))
+
+    def tune(self, sample: bytes) -> None:
+        """Re-select prefilter windows from a text sample (call before creating a Scanner); results never change."""
+        if lib().hg_db_tune(self._h, sample, len(sample)) != 0:
+            raise CompileError("hg_db_tune failed")
 
     def info(self) -> dict:
         out = HgDbInfo()

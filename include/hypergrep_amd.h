@@ -161,6 +161,10 @@ typedef struct hg_db_info {
  * writes "<expression index>: <reason>" to err. */
 int hg_db_compile(const char *const *expressions, const unsigned int *flags, const unsigned int *ids,
                   unsigned int n, hg_database_t **db, char *err, size_t errlen);
+/* Optional: re-select the literal windows of the prefilter using byte statistics of a host-side text sample (any
+ * prefix of what will be scanned) and rebuild the filter tables.  Never changes results, only how often the slower
+ * stages run.  Call before hg_scanner_create. */
+int hg_db_tune(hg_database_t *db, const void *sample, size_t nbytes);
 void hg_db_release(hg_database_t *db);
 int hg_db_info(const hg_database_t *db, hg_db_info_t *info);
 

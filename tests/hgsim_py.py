@@ -70,6 +70,10 @@ class Db:
         lib().hgsim_info(self.h, out)
         return dict(zip(("npatterns", "nfactors", "nwindows", "nslow", "fold_mask", "max_nw"), out))
 
+    def tune(self, sample: bytes) -> int:
+        lib().hgsim_tune.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+        return lib().hgsim_tune(self.h, sample, len(sample))
+
     def tier(self, i: int) -> int:
         return lib().hgsim_pattern_tier(self.h, i)
 
@@ -80,6 +84,8 @@ class Db:
 
     def scan(self, data: bytes, buffer_size: int = 262140):
         """Returns (hits, stats); hits = list of (line_no, id, to, start, len)."""
+        if not self.h:
+            raise RuntimeError(f"database did not compile: {self.error}")
         out = ctypes.POINTER(SimHit)()
         stats = (ctypes.c_uint64 * 5)()
         n = lib().hgsim_scan(self.h, data, len(data), buffer_size, ctypes.byref(out), stats)

@@ -7,7 +7,9 @@
 // so the compiler's tables and the shared device logic can be checked against the oracle without a GPU.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -34,13 +36,17 @@ void *hgsim_compile(const char *const *exprs, const unsigned *flags, const unsig
   }
   return db;
 }
+int hgsim_tune(void *h, const uint8_t *sample, size_t n) {
+  std::string e;
+  return hgc_tune(static_cast<HgDb *>(h), sample, n, &e);
+}
 void hgsim_free(void *h) { hgc_free(static_cast<HgDb *>(h)); }
 
 void hgsim_info(void *h, uint32_t *out) {  // npatterns, nfactors, nwindows, nslow, fold_mask, max_nw
   HgDb *db = static_cast<HgDb *>(h);
   out[0] = db->patterns.size();
-  out[1] = db->factors.size();
-  out[2] = db->windows.size();
+  out[1] = db->nreal_factors;
+  out[2] = db->nreal_factors ? db->windows.size() : 0;
   out[3] = db->slow.size();
   out[4] = db->fold_mask;
   out[5] = db->max_nw;
@@ -85,6 +91,7 @@ long hgsim_scan(void *h, const uint8_t *data, uint64_t nbytes, int buffer_size, 
   std::vector<HgTileBase> bases(ntiles + 1);
   std::vector<HgCand> cands;
   uint64_t bitmap_hits = 0, level2_hits = 0;
+  std::map<uint32_t, uint64_t> l1_hist;
   // ---- stream pass
   for (uint64_t t = 0; t < ntiles; t++) {
     uint64_t base = t * HG_TILE_BYTES;
@@ -105,26 +112,28 @@ long hgsim_scan(void *h, const uint8_t *data, uint64_t nbytes, int buffer_size, 
           }
         s.nl_count += hg_popc(m);
       }
-      const uint32_t folded = w | v.fold_mask, byte_mask = ((1u << db->filter_log2) - 1u) << 2;
-      const uint32_t fp = hg_hash_window(folded);
+      const uint32_t folded = (w | v.fold_mask) & HG_WINDOW_MASK, byte_mask = ((1u << db->filter_log2) - 1u) << 2;
+      // bytes outside the text read as zero, like the kernel's masked tail
+      auto dword_at = [&](int64_t p) -> uint32_t {
+        uint32_t x = 0;
+        for (int b = 0; b < 4; b++)
+          if (p + b >= 0 && static_cast<uint64_t>(p + b) < nbytes) x |= static_cast<uint32_t>(data[p + b]) << (8 * b);
+        return x;
+      };
+      // first level: window hash
+      const uint32_t key0 = hg_hash_window(folded);
       const uint32_t sla = hg_slot(folded, db->weights_a, byte_mask) >> 2, slb = hg_slot(folded, db->weights_b, byte_mask) >> 2;
-      const bool ha = db->filter[sla] == fp, hb = db->filter[slb] == fp;
+      const bool ha = db->filter[sla] == key0, hb = db->filter[slb] == key0;
       if (ha || hb) {
         bitmap_hits++;
-        // second level: neighbour dwords (bytes outside the text read as zero, like the kernel's masked tail)
-        auto dword_at = [&](int64_t p) -> uint32_t {
-          uint32_t x = 0;
-          for (int b = 0; b < 4; b++)
-            if (p + b >= 0 && static_cast<uint64_t>(p + b) < nbytes) x |= static_cast<uint32_t>(data[p + b]) << (8 * b);
-          return x;
-        };
-        const uint32_t pf = dword_at(static_cast<int64_t>(pos) - 4) | v.fold_mask, nf = dword_at(static_cast<int64_t>(pos) + 4) | v.fold_mask;
+        if (getenv("HGSIM_DUMP")) l1_hist[folded]++;
+        const uint32_t pf = dword_at(static_cast<int64_t>(pos) - 4) | v.fold_mask, nf = dword_at(static_cast<int64_t>(pos) + HG_WINDOW_BYTES) | v.fold_mask;
         // the kernel cannot see across its 16 KiB tile edge or the first/last lane of a 1 KiB segment: treat as pass there
         const bool edge_prev = (pos % 1024) == 0, edge_next = (pos % 1024) == 1020;
         auto pass = [&](uint32_t sl) {
           HgFilterExt e = db->ext[sl];
           if (edge_prev) e.pm = 0;
-          if (edge_next) e.nm = 0;
+          if (edge_next) e.nm &= (HG_WINDOW_BYTES == 4 ? 0u : 0xFFu);  // the last lane sees at most its own dword's top byte
           e.pv &= e.pm;
           e.nv &= e.nm;
           return hg_ext_pass(e, pf, nf);
@@ -138,6 +147,15 @@ long hgsim_scan(void *h, const uint8_t *data, uint64_t nbytes, int buffer_size, 
     if (bs1 < HG_TILE_BYTES && s.nl_count >= 2)  // ~ hg_tile_inner_kernel
       s.inner = static_cast<uint32_t>(hg_inner_pieces(data, base + s.first_nl + 1, base + s.last_nl + 1, bs1));
     sums[t] = s;
+  }
+  if (getenv("HGSIM_DUMP")) {
+    std::vector<std::pair<uint64_t, uint32_t>> top;
+    for (auto &kv : l1_hist) top.push_back({kv.second, kv.first});
+    std::sort(top.rbegin(), top.rend());
+    for (size_t i = 0; i < top.size() && i < 12; i++) {
+      uint32_t x = top[i].second;
+      fprintf(stderr, "L1 window '%c%c%c%c' x%llu\n", x & 0xff, (x >> 8) & 0xff, (x >> 16) & 0xff, x >> 24, (unsigned long long)top[i].first);
+    }
   }
   // ---- tile scan
   HgTileBase st{0, 0};
