@@ -34,6 +34,7 @@ def main() -> None:
     ap.add_argument("--gib", type=float, default=32.0, help="GiB of text per GPU (the headline workload is 32)")
     ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c5"])
     ap.add_argument("--ids", default="distinct", choices=["distinct", "shared"], help="pattern ids 0..n-1 or all 0 (grep() semantics)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only for rehearsals)")
     ap.add_argument("--no-tune", action="store_true", help="keep the static window selection (no text sample)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     args = ap.parse_args()
@@ -50,11 +51,16 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the scan path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():  # rehearsal of N ranks on fewer GPUs (never the case under the driver)
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)  # RCCL over xGMI
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend=args.backend)
 
     spec = {"c1": benchspec.c1_spec, "c2": benchspec.c2_spec, "c3": benchspec.c3_spec, "c5": benchspec.c5_spec}[args.workload]
     patterns, needles, hpm = spec()

@@ -19,11 +19,11 @@ struct HgDeferred {
   uint32_t pattern;
   uint32_t rank;
 };
-enum { HG_CNT_CANDS = 0, HG_CNT_HITS = 1, HG_CNT_CAND_NEED = 2, HG_CNT_HIT_NEED = 3, HG_CNT_WORDS = 8 };
+enum { HG_CNT_CANDS = 0, HG_CNT_HITS = 1, HG_CNT_CAND_NEED = 2, HG_CNT_HIT_NEED = 3, HG_CNT_DEFER_NEED = 4, HG_CNT_WORDS = 8 };
 
 struct HgStreamArgs {
   const uint8_t *text;
-  uint64_t nbytes, ntiles;
+  uint64_t nbytes, tile_begin, tile_end;  // the launch covers tiles [tile_begin, tile_end) of the text
   HgDbView db;
   const uint32_t *filter;  // 1 << filter_log2 window-hash slots
   const HgFilterExt *ext;  // per slot: neighbour-dword conditions
@@ -37,7 +37,7 @@ struct HgStreamArgs {
 
 struct HgConfirmArgs {
   const uint8_t *text;
-  uint64_t nbytes, ntiles, bs1;
+  uint64_t nbytes, tile_begin, tile_end, bs1;
   HgDbView db;
   const HgTileSum *sums;
   const HgTileBase *bases;
@@ -117,4 +117,10 @@ class HgScanner {
   uint32_t *h_counters_ = nullptr;  // pinned
   HgTileBase *h_final_ = nullptr;   // pinned
   hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
+  // chunked pipeline: the stream pass of chunk c+1 overlaps the verify / confirm passes of chunk c
+  static constexpr int kMaxChunks = 16;
+  hipStream_t side_stream_ = nullptr;
+  hipEvent_t ev_k1_begin_[kMaxChunks] = {}, ev_k1_end_[kMaxChunks] = {}, ev_side_done_[kMaxChunks] = {};
+  uint32_t *d_seg_count2_ = nullptr;  // second set for double buffering
+  HgCand *d_cands2_ = nullptr;
 };

@@ -14,11 +14,11 @@
 // kernels (hg_kernels.hip)
 void hg_launch_stream(const HgStreamArgs &a, uint32_t grid, hipStream_t stream);
 int hg_stream_blocks_per_cu(uint32_t filter_log2);
-__global__ void hg_tile_reduce_kernel(const HgTileSum *sums, uint64_t ntiles, uint64_t bs1, HgTileElem *agg);
-__global__ void hg_tile_spine_kernel(const HgTileElem *agg, uint32_t nblocks, uint64_t bs1, HgTileBase init, HgTileBase *block_base,
-                                     HgTileBase *final_state);
-__global__ void hg_tile_apply_kernel(const HgTileSum *sums, uint64_t ntiles, uint64_t bs1, const HgTileBase *block_base, HgTileBase *bases);
-__global__ void hg_tile_inner_kernel(const uint8_t *text, HgTileSum *sums, uint64_t ntiles, uint64_t bs1);
+__global__ void hg_tile_reduce_kernel(const HgTileSum *sums, uint64_t tile_begin, uint64_t tile_end, uint64_t bs1, HgTileElem *agg);
+__global__ void hg_tile_spine_kernel(const HgTileElem *agg, uint32_t nblocks, uint64_t bs1, HgTileBase *block_base, HgTileBase *state);
+__global__ void hg_tile_apply_kernel(const HgTileSum *sums, uint64_t tile_begin, uint64_t tile_end, uint64_t bs1, const HgTileBase *block_base,
+                                     HgTileBase *bases);
+__global__ void hg_tile_inner_kernel(const uint8_t *text, HgTileSum *sums, uint64_t tile_begin, uint64_t tile_end, uint64_t bs1);
 __global__ void hg_verify_kernel(HgConfirmArgs a);
 __global__ void hg_confirm_kernel(HgConfirmArgs a);
 __global__ void hg_confirm_ctx_kernel(HgConfirmArgs a);
@@ -104,6 +104,12 @@ int HgScanner::create(const HgDb *db, int device, HgScanner **out, std::string *
   HG_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_counters_), (HG_CNT_WORDS + 4 + HG_DEFER_SHARDS) * 4), "alloc pinned");
   HG_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_final_), sizeof(HgTileBase)), "alloc pinned");
   for (auto &ev : s->ev_) HG_TRY(hipEventCreate(&ev), "hipEventCreate");
+  HG_TRY(hipStreamCreateWithFlags(&s->side_stream_, hipStreamNonBlocking), "hipStreamCreate");
+  for (int i = 0; i < kMaxChunks; i++) {
+    HG_TRY(hipEventCreate(&s->ev_k1_begin_[i]), "hipEventCreate");
+    HG_TRY(hipEventCreate(&s->ev_k1_end_[i]), "hipEventCreate");
+    HG_TRY(hipEventCreateWithFlags(&s->ev_side_done_[i], hipEventDisableTiming), "hipEventCreate");
+  }
 #undef HG_TRY
   *out = s.release();
   return HG_OK;
@@ -113,13 +119,19 @@ HgScanner::~HgScanner() {
   (void)hipSetDevice(device_);
   void *ptrs[] = {d_patterns_, d_pool_, d_factors_, d_windows_, d_bucket_, d_filter_, d_ext_, d_slow_, d_sums_, d_bases_, d_block_base_,
                   d_final_, d_agg_, d_cands_, d_hits_raw_, d_hits_sorted_, d_hits_out_, d_aux_raw_, d_aux_sorted_, d_aux_out_,
-                  d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, d_keep_, d_counters_, d_selected_, d_temp_, d_seg_count_, d_pflags_, d_deferred_, d_defer_count_};
+                  d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, d_keep_, d_counters_, d_selected_, d_temp_, d_seg_count_, d_pflags_, d_deferred_, d_defer_count_, d_seg_count2_, d_cands2_};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (h_counters_) (void)hipHostFree(h_counters_);
   if (h_final_) (void)hipHostFree(h_final_);
   for (auto &ev : ev_)
     if (ev) (void)hipEventDestroy(ev);
+  for (int i = 0; i < kMaxChunks; i++) {
+    if (ev_k1_begin_[i]) (void)hipEventDestroy(ev_k1_begin_[i]);
+    if (ev_k1_end_[i]) (void)hipEventDestroy(ev_k1_end_[i]);
+    if (ev_side_done_[i]) (void)hipEventDestroy(ev_side_done_[i]);
+  }
+  if (side_stream_) (void)hipStreamDestroy(side_stream_);
 }
 
 int HgScanner::alloc_cands(uint64_t n) {
@@ -127,6 +139,9 @@ int HgScanner::alloc_cands(uint64_t n) {
   if (d_cands_) (void)hipFree(d_cands_);
   d_cands_ = nullptr;
   if (fail(hipMalloc(reinterpret_cast<void **>(&d_cands_), n * sizeof(HgCand)), "workspace alloc (candidates)")) return HG_ERR_HIP;
+  if (d_cands2_) (void)hipFree(d_cands2_);
+  d_cands2_ = nullptr;
+  if (fail(hipMalloc(reinterpret_cast<void **>(&d_cands2_), n * sizeof(HgCand)), "workspace alloc (candidates)")) return HG_ERR_HIP;
   if (d_deferred_) (void)hipFree(d_deferred_);
   d_deferred_ = nullptr;
   if (fail(hipMalloc(reinterpret_cast<void **>(&d_deferred_), n * sizeof(HgDeferred)), "workspace alloc (deferred)")) return HG_ERR_HIP;
@@ -172,7 +187,7 @@ int HgScanner::ensure(uint64_t nbytes) {
   }
   if (!d_seg_count_) {
     max_segs_ = static_cast<uint32_t>(num_cus_) * 16;
-    if (re(d_seg_count_, max_segs_) || re(d_defer_count_, HG_DEFER_SHARDS)) return HG_ERR_HIP;
+    if (re(d_seg_count_, max_segs_) || re(d_seg_count2_, max_segs_) || re(d_defer_count_, HG_DEFER_SHARDS)) return HG_ERR_HIP;
   }
   // one candidate / hit per KiB of text to start with; grows (and the pass repeats) on overflow
   uint64_t want = std::max<uint64_t>(nbytes / 1024, 1u << 16);
@@ -185,93 +200,131 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
                         HgScanOutput *out, bool *overflow) {
   *overflow = false;
   const uint64_t ntiles = (nbytes + HG_TILE_BYTES - 1) / HG_TILE_BYTES;
-  const uint32_t nblocks = static_cast<uint32_t>((ntiles + TS_BLOCK_TILES - 1) / TS_BLOCK_TILES);
 #define HG_TRY(call, what) \
   if (fail((call), what)) return HG_ERR_HIP;
   HG_TRY(hipMemsetAsync(d_counters_, 0, HG_CNT_WORDS * 4, stream), "memset counters");
   HG_TRY(hipEventRecord(ev_[0], stream), "event");
 
+  // Chunked pipeline (line mode, large buffers): the text is cut into tile-aligned chunks; the stream pass of chunk c+1
+  // runs on the caller's stream while tile scan + verify + confirm of chunk c run on a side stream.  The stream pass
+  // then leaves a quarter of the wave slots free so that the latency-bound side work is co-resident.
+  const bool has_anchored = db_->patterns.size() > db_->slow.size();
+  uint32_t nchunks = 1;
+  // measured on MI355X (32 GiB, 256 patterns): 8 GiB chunks 15.2 ms, 2 GiB chunks 20.8 ms, no chunking 17.6 ms per pass —
+  // the latency-bound side kernels need a few hundred thousand candidates per launch to fill the chip
+  constexpr uint64_t kChunkTiles = 8ull << (30 - HG_TILE_SHIFT);
+  if (!block_mode && ntiles >= 2 * kChunkTiles) nchunks = static_cast<uint32_t>(std::min<uint64_t>(kMaxChunks, ntiles / kChunkTiles));
+  uint64_t chunk_tiles = ((ntiles + nchunks - 1) / nchunks + TS_BLOCK_TILES - 1) / TS_BLOCK_TILES * TS_BLOCK_TILES;
+  if (const char *env = std::getenv("HG_CHUNK_TILES")) {  // tests: force the chunked pipeline on small buffers
+    uint64_t v = std::strtoull(env, nullptr, 10);
+    if (!block_mode && v >= TS_BLOCK_TILES) chunk_tiles = std::max<uint64_t>(v / TS_BLOCK_TILES * TS_BLOCK_TILES, (ntiles + kMaxChunks - 1) / kMaxChunks / TS_BLOCK_TILES * TS_BLOCK_TILES + TS_BLOCK_TILES);
+  }
+  nchunks = ntiles ? static_cast<uint32_t>((ntiles + chunk_tiles - 1) / chunk_tiles) : 1;
+  const bool piped = nchunks > 1;
+
   uint32_t wgs = 1, confirm_blocks = 1, always_blocks = 1;
+  out->ms_stream = 0;
   if (ntiles) {
     if (stream_wgs_per_cu_ == 0) stream_wgs_per_cu_ = hg_stream_blocks_per_cu(db_->filter_log2);
-    wgs = static_cast<uint32_t>(std::min<uint64_t>((ntiles + STREAM_WG_WAVES - 1) / STREAM_WG_WAVES,
-                                                   std::min<uint64_t>(static_cast<uint64_t>(num_cus_) * stream_wgs_per_cu_, max_segs_)));
-    HgStreamArgs sa{};
-    sa.text = text;
-    sa.nbytes = nbytes;
-    sa.ntiles = ntiles;
-    sa.db = view_;
-    sa.filter = static_cast<const uint32_t *>(d_filter_);
-    sa.filter_log2 = db_->filter_log2;
-    sa.weights_a = db_->weights_a;
-    sa.weights_b = db_->weights_b;
-    sa.ext = static_cast<const HgFilterExt *>(d_ext_);
-    sa.sums = d_sums_;
-    sa.cands = d_cands_;
-    sa.seg_count = d_seg_count_;
-    sa.cand_seg_cap = cand_cap_ / wgs;
-    sa.counters = d_counters_;
-    HG_TRY(hipEventRecord(ev_[1], stream), "event");
-    hg_launch_stream(sa, wgs, stream);
-    HG_TRY(hipGetLastError(), "hg_stream_kernel launch");
-    HG_TRY(hipEventRecord(ev_[2], stream), "event");
+    const uint32_t per_cu = piped ? std::max(1, stream_wgs_per_cu_ - 1) : stream_wgs_per_cu_;
+    wgs = static_cast<uint32_t>(std::min<uint64_t>((std::min<uint64_t>(chunk_tiles, ntiles) + STREAM_WG_WAVES - 1) / STREAM_WG_WAVES,
+                                                   std::min<uint64_t>(static_cast<uint64_t>(num_cus_) * per_cu, max_segs_)));
+    hipStream_t side = piped ? side_stream_ : stream;
+    HgTileBase init{0, line_base};
+    *h_final_ = init;
+    HG_TRY(hipMemcpyAsync(d_final_, h_final_, sizeof(HgTileBase), hipMemcpyHostToDevice, stream), "upload scan state");
+    if (piped) {  // side stream starts after the counters / state are in place
+      HG_TRY(hipEventRecord(ev_side_done_[kMaxChunks - 1], stream), "event");
+      HG_TRY(hipStreamWaitEvent(side, ev_side_done_[kMaxChunks - 1], 0), "stream wait");
+    }
+    for (uint32_t c = 0; c < nchunks; c++) {
+      const uint64_t t0 = static_cast<uint64_t>(c) * chunk_tiles, t1 = std::min<uint64_t>(t0 + chunk_tiles, ntiles);
+      const uint32_t set = piped ? (c & 1u) : 0u;
+      HgCand *cands = set ? d_cands2_ : d_cands_;
+      uint32_t *seg_count = set ? d_seg_count2_ : d_seg_count_;
+      if (piped && c >= 2) HG_TRY(hipStreamWaitEvent(stream, ev_side_done_[c - 2], 0), "stream wait");  // buffer set is free again
 
-    if (!block_mode) {
-      if (bs1 < HG_TILE_BYTES) {  // small-buffer mode: lines inside a tile can split, re-price the tile summaries
-        uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((ntiles + 255) / 256, 4096));
-        hipLaunchKernelGGL(hg_tile_inner_kernel, dim3(blocks), dim3(256), 0, stream, text, d_sums_, ntiles, bs1);
+      HgStreamArgs sa{};
+      sa.text = text;
+      sa.nbytes = nbytes;
+      sa.tile_begin = t0;
+      sa.tile_end = t1;
+      sa.db = view_;
+      sa.filter = static_cast<const uint32_t *>(d_filter_);
+      sa.filter_log2 = db_->filter_log2;
+      sa.weights_a = db_->weights_a;
+      sa.weights_b = db_->weights_b;
+      sa.ext = static_cast<const HgFilterExt *>(d_ext_);
+      sa.sums = d_sums_;
+      sa.cands = cands;
+      sa.seg_count = seg_count;
+      sa.cand_seg_cap = cand_cap_ / wgs;
+      sa.counters = d_counters_;
+      HG_TRY(hipEventRecord(piped ? ev_k1_begin_[c] : ev_[1], stream), "event");
+      hg_launch_stream(sa, wgs, stream);
+      HG_TRY(hipGetLastError(), "hg_stream_kernel launch");
+      HG_TRY(hipEventRecord(piped ? ev_k1_end_[c] : ev_[2], stream), "event");
+      if (piped) HG_TRY(hipStreamWaitEvent(side, ev_k1_end_[c], 0), "stream wait");
+
+      HgConfirmArgs ca{};
+      ca.text = text;
+      ca.nbytes = nbytes;
+      ca.tile_begin = t0;
+      ca.tile_end = t1;
+      ca.bs1 = bs1;
+      ca.db = view_;
+      ca.sums = d_sums_;
+      ca.bases = d_bases_;
+      ca.cands = cands;
+      ca.seg_count = seg_count;
+      ca.hits = d_hits_raw_;
+      ca.aux = d_aux_raw_;
+      ca.tmp_hits = d_hits_out_;  // free until the final select
+      ca.tmp_aux = d_aux_out_;
+      ca.cand_seg_cap = sa.cand_seg_cap;
+      ca.hit_cap = hit_cap_;
+      ca.counters = d_counters_;
+      if (block_mode) {
+        HG_TRY(hipMemsetAsync(d_pflags_, 0, db_->patterns.size() * 4, side), "memset pattern flags");
+        if (has_anchored) hipLaunchKernelGGL(hg_block_mark_kernel, dim3(wgs), dim3(256), 0, side, ca, d_pflags_);
+        always_blocks = static_cast<uint32_t>((db_->patterns.size() + 255) / 256);
+        ca.hit_seg_cap = hit_cap_ / always_blocks;
+        hipLaunchKernelGGL(hg_block_scan_kernel, dim3(always_blocks), dim3(256), 0, side, ca, d_pflags_);
+        HG_TRY(hipGetLastError(), "block-mode launch");
+      } else {
+        const uint64_t span = t1 - t0;
+        const uint32_t nblocks = static_cast<uint32_t>((span + TS_BLOCK_TILES - 1) / TS_BLOCK_TILES);
+        if (bs1 < HG_TILE_BYTES) {  // small-buffer mode: lines inside a tile can split, re-price the tile summaries
+          uint32_t blocks = static_cast<uint32_t>(std::min<uint64_t>((span + 255) / 256, 4096));
+          hipLaunchKernelGGL(hg_tile_inner_kernel, dim3(blocks), dim3(256), 0, side, text, d_sums_, t0, t1, bs1);
+        }
+        hipLaunchKernelGGL(hg_tile_reduce_kernel, dim3(nblocks), dim3(256), 0, side, d_sums_, t0, t1, bs1, d_agg_);
+        hipLaunchKernelGGL(hg_tile_spine_kernel, dim3(1), dim3(256), 0, side, d_agg_, nblocks, bs1, d_block_base_, d_final_);
+        hipLaunchKernelGGL(hg_tile_apply_kernel, dim3(nblocks), dim3(256), 0, side, d_sums_, t0, t1, bs1, d_block_base_, d_bases_);
+        HG_TRY(hipGetLastError(), "tile scan launch");
+        if (has_anchored) {
+          confirm_blocks = wgs * HG_CONFIRM_SPLIT;  // HG_CONFIRM_SPLIT blocks share candidate segment b
+          ca.hit_seg_cap = hit_cap_ / confirm_blocks;
+          ca.deferred = d_deferred_;
+          ca.defer_count = d_defer_count_;
+          ca.defer_shard_cap = cand_cap_ / HG_DEFER_SHARDS;
+          HG_TRY(hipMemsetAsync(d_defer_count_, 0, HG_DEFER_SHARDS * 4, side), "memset deferred counts");
+          hipLaunchKernelGGL(hg_verify_kernel, dim3(confirm_blocks), dim3(256), 0, side, ca);
+          if (db_->n_confirm_mode[1]) hipLaunchKernelGGL(hg_confirm_kernel, dim3(confirm_blocks), dim3(256), 0, side, ca);
+          if (db_->n_confirm_mode[2]) hipLaunchKernelGGL(hg_confirm_ctx_kernel, dim3(confirm_blocks), dim3(256), 0, side, ca);
+          if (db_->n_confirm_mode[3]) hipLaunchKernelGGL(hg_confirm_generic_kernel, dim3(confirm_blocks), dim3(256), 0, side, ca);
+          HG_TRY(hipGetLastError(), "confirm launch");
+        }
+        if (!db_->slow.empty()) {
+          always_blocks = static_cast<uint32_t>(std::min<uint64_t>((span + 3) / 4, static_cast<uint64_t>(num_cus_) * 8));
+          ca.hit_seg_cap = hit_cap_ / always_blocks;
+          hipLaunchKernelGGL(hg_always_on_kernel, dim3(always_blocks), dim3(256), 0, side, ca);
+          HG_TRY(hipGetLastError(), "hg_always_on_kernel launch");
+        }
       }
-      HgTileBase init{0, line_base};
-      hipLaunchKernelGGL(hg_tile_reduce_kernel, dim3(nblocks), dim3(256), 0, stream, d_sums_, ntiles, bs1, d_agg_);
-      hipLaunchKernelGGL(hg_tile_spine_kernel, dim3(1), dim3(256), 0, stream, d_agg_, nblocks, bs1, init, d_block_base_, d_final_);
-      hipLaunchKernelGGL(hg_tile_apply_kernel, dim3(nblocks), dim3(256), 0, stream, d_sums_, ntiles, bs1, d_block_base_, d_bases_);
-      HG_TRY(hipGetLastError(), "tile scan launch");
+      if (piped) HG_TRY(hipEventRecord(ev_side_done_[c], side), "event");
     }
-
-    HgConfirmArgs ca{};
-    ca.text = text;
-    ca.nbytes = nbytes;
-    ca.ntiles = ntiles;
-    ca.bs1 = bs1;
-    ca.db = view_;
-    ca.sums = d_sums_;
-    ca.bases = d_bases_;
-    ca.cands = d_cands_;
-    ca.seg_count = d_seg_count_;
-    ca.hits = d_hits_raw_;
-    ca.aux = d_aux_raw_;
-    ca.tmp_hits = d_hits_out_;  // free until the final select
-    ca.tmp_aux = d_aux_out_;
-    ca.cand_seg_cap = sa.cand_seg_cap;
-    ca.hit_cap = hit_cap_;
-    ca.counters = d_counters_;
-    if (block_mode) {
-      HG_TRY(hipMemsetAsync(d_pflags_, 0, db_->patterns.size() * 4, stream), "memset pattern flags");
-      if (db_->patterns.size() > db_->slow.size()) hipLaunchKernelGGL(hg_block_mark_kernel, dim3(wgs), dim3(256), 0, stream, ca, d_pflags_);
-      always_blocks = static_cast<uint32_t>((db_->patterns.size() + 255) / 256);
-      ca.hit_seg_cap = hit_cap_ / always_blocks;
-      hipLaunchKernelGGL(hg_block_scan_kernel, dim3(always_blocks), dim3(256), 0, stream, ca, d_pflags_);
-      HG_TRY(hipGetLastError(), "block-mode launch");
-    } else if (db_->patterns.size() > db_->slow.size()) {
-      confirm_blocks = wgs * HG_CONFIRM_SPLIT;  // HG_CONFIRM_SPLIT blocks share candidate segment b
-      ca.hit_seg_cap = hit_cap_ / confirm_blocks;
-      ca.deferred = d_deferred_;
-      ca.defer_count = d_defer_count_;
-      ca.defer_shard_cap = cand_cap_ / HG_DEFER_SHARDS;
-      HG_TRY(hipMemsetAsync(d_defer_count_, 0, HG_DEFER_SHARDS * 4, stream), "memset deferred counts");
-      hipLaunchKernelGGL(hg_verify_kernel, dim3(confirm_blocks), dim3(256), 0, stream, ca);
-      if (db_->n_confirm_mode[1]) hipLaunchKernelGGL(hg_confirm_kernel, dim3(confirm_blocks), dim3(256), 0, stream, ca);
-      if (db_->n_confirm_mode[2]) hipLaunchKernelGGL(hg_confirm_ctx_kernel, dim3(confirm_blocks), dim3(256), 0, stream, ca);
-      if (db_->n_confirm_mode[3]) hipLaunchKernelGGL(hg_confirm_generic_kernel, dim3(confirm_blocks), dim3(256), 0, stream, ca);
-      HG_TRY(hipMemcpyAsync(h_counters_ + HG_CNT_WORDS + 4, d_defer_count_, HG_DEFER_SHARDS * 4, hipMemcpyDeviceToHost, stream), "copy deferred counts");
-      HG_TRY(hipGetLastError(), "hg_confirm_kernel launch");
-    }
-    if (!block_mode && !db_->slow.empty()) {
-      always_blocks = static_cast<uint32_t>(std::min<uint64_t>((ntiles + 3) / 4, static_cast<uint64_t>(num_cus_) * 8));
-      ca.hit_seg_cap = hit_cap_ / always_blocks;
-      hipLaunchKernelGGL(hg_always_on_kernel, dim3(always_blocks), dim3(256), 0, stream, ca);
-      HG_TRY(hipGetLastError(), "hg_always_on_kernel launch");
-    }
+    if (piped) HG_TRY(hipStreamWaitEvent(stream, ev_side_done_[nchunks - 1], 0), "stream wait");
     if (!block_mode) HG_TRY(hipMemcpyAsync(h_final_, d_final_, sizeof(HgTileBase), hipMemcpyDeviceToHost, stream), "copy state");
   } else {
     HG_TRY(hipEventRecord(ev_[1], stream), "event");
@@ -281,13 +334,17 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   }
   HG_TRY(hipMemcpyAsync(h_counters_, d_counters_, HG_CNT_WORDS * 4, hipMemcpyDeviceToHost, stream), "copy counters");
   HG_TRY(hipStreamSynchronize(stream), "stream sync (scan kernels)");
+  if (piped) {
+    for (uint32_t c = 0; c < nchunks; c++) {
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, ev_k1_begin_[c], ev_k1_end_[c]);
+      out->ms_stream += ms;
+    }
+  }
 
   const uint64_t n_cands = h_counters_[HG_CNT_CANDS], n_raw = h_counters_[HG_CNT_HITS];
   const uint64_t cand_need = h_counters_[HG_CNT_CAND_NEED], hit_need = h_counters_[HG_CNT_HIT_NEED];
-  uint64_t defer_need = 0;
-  if (ntiles && !block_mode && db_->patterns.size() > db_->slow.size())
-    for (uint32_t i = 0; i < HG_DEFER_SHARDS; i++)
-      if (h_counters_[HG_CNT_WORDS + 4 + i] > cand_cap_ / HG_DEFER_SHARDS) defer_need = std::max<uint64_t>(defer_need, h_counters_[HG_CNT_WORDS + 4 + i]);
+  const uint64_t defer_need = h_counters_[HG_CNT_DEFER_NEED];
   if (cand_need || defer_need || hit_need || n_raw > hit_cap_) {
     // a private segment (or the compact hit array) was too small: grow and let the caller repeat the pass
     if (cand_need || defer_need) {
@@ -345,9 +402,8 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   out->n_raw_hits = n_raw;
   out->d_hits = d_hits_out_;
   out->d_aux = d_aux_out_;
-  out->ms_stream = 0;
   out->ms_total = 0;
-  (void)hipEventElapsedTime(&out->ms_stream, ev_[1], ev_[2]);
+  if (out->ms_stream == 0) (void)hipEventElapsedTime(&out->ms_stream, ev_[1], ev_[2]);
   (void)hipEventElapsedTime(&out->ms_total, ev_[0], ev_[3]);
 #undef HG_TRY
   return HG_OK;

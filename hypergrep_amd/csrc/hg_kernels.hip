@@ -88,7 +88,7 @@ template <int LOG2>
 struct Probe {
   static constexpr uint32_t BYTE_MASK = ((1u << LOG2) - 1u) << 2;
   // First level for the lane's four dwords: a slot matches if it holds the window's hash C.
-  // ANY_ONLY: non-zero iff any of the four windows matched (hot path); else bit k set iff window k matched.
+  // ANY_ONLY: non-zero iff any of the four windows matched (hot path); else per-window, per-slot match bits.
   template <bool ANY_ONLY>
   __device__ __forceinline__ static uint32_t probe4(const uint32_t *filter, uint32_t fold, uint32_t wa, uint32_t wb, uint4 v) {
     const uint32_t f0 = v.x | fold, f1 = v.y | fold, f2 = v.z | fold, f3 = v.w | fold;
@@ -100,49 +100,38 @@ struct Probe {
     const uint8_t *base = reinterpret_cast<const uint8_t *>(filter);
     auto at = [&](uint32_t h) { return *reinterpret_cast<const uint32_t *>(base + (h & BYTE_MASK)); };
     const uint32_t ta0 = at(a0), tb0 = at(b0), ta1 = at(a1), tb1 = at(b1), ta2 = at(a2), tb2 = at(b2), ta3 = at(a3), tb3 = at(b3);
-    const bool m0 = ta0 == c0 || tb0 == c0, m1 = ta1 == c1 || tb1 == c1, m2 = ta2 == c2 || tb2 == c2, m3 = ta3 == c3 || tb3 == c3;
-    if (ANY_ONLY) return (m0 || m1 || m2 || m3) ? 1u : 0u;
-    return (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u) | (m3 ? 8u : 0u);
+    if (ANY_ONLY) return (ta0 == c0 || tb0 == c0 || ta1 == c1 || tb1 == c1 || ta2 == c2 || tb2 == c2 || ta3 == c3 || tb3 == c3) ? 1u : 0u;
+    // bits 0..3: slot A of window k matched; bits 4..7: slot B
+    return (ta0 == c0 ? 1u : 0u) | (ta1 == c1 ? 2u : 0u) | (ta2 == c2 ? 4u : 0u) | (ta3 == c3 ? 8u : 0u) | (tb0 == c0 ? 16u : 0u) |
+           (tb1 == c1 ? 32u : 0u) | (tb2 == c2 ? 64u : 0u) | (tb3 == c3 ? 128u : 0u);
   }
 };
 
-// Second level, entered when some lane's first level matched: the dwords before and after the window must
-// agree (byte-masked) with what the slot's literals have there.  `hits`: bit k = window k passed the first level.
-// Returns bit k set iff window k survives.
+// Second level, entered when some lane's first level matched: the 4 bytes before and after the window must
+// agree (byte-masked) with what the matching slot's literals have there.  `l1`: bits 0..3 = slot A of window k
+// matched, bits 4..7 = slot B.  Returns bit k set iff window k survives.
 template <int LOG2>
-__device__ __forceinline__ uint32_t level2_filter(const uint32_t *filter, const HgFilterExt *ext, uint32_t fold, uint32_t wa, uint32_t wb, uint4 v,
-                                                  uint32_t left, uint32_t right, uint32_t lane, uint32_t hits) {
+__device__ __forceinline__ uint32_t level2_filter(const HgFilterExt *ext, uint32_t fold, uint32_t wa, uint32_t wb, uint4 v, uint32_t left,
+                                                  uint32_t right, uint32_t lane, uint32_t l1) {
   constexpr uint32_t BYTE_MASK = ((1u << LOG2) - 1u) << 2;
   const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-  const uint8_t *base = reinterpret_cast<const uint8_t *>(filter);
   uint32_t out = 0;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    if ((hits >> k) & 1u) {
+    const bool ha = (l1 >> k) & 1u, hb = (l1 >> (k + 4)) & 1u;
+    if (ha || hb) {
       const uint32_t f = w[k] | fold;
-      const uint32_t sa = hg_dot4(f, wa) & BYTE_MASK, sb = hg_dot4(f, wb) & BYTE_MASK;
-      const uint32_t fp = hg_dot4(f, HG_HASH_WEIGHTS);
-      const bool ha = *reinterpret_cast<const uint32_t *>(base + sa) == fp;
-      const bool hb = *reinterpret_cast<const uint32_t *>(base + sb) == fp;
-      // the 4 bytes before the window, and the 4 bytes after it (top byte of its own dword + 3 of the next)
+      // both conditions are fetched at once (one LDS round trip); a slot that did not match counts as failed
+      const HgFilterExt ea = ext[(hg_dot4(f, wa) & BYTE_MASK) >> 2], eb = ext[(hg_dot4(f, wb) & BYTE_MASK) >> 2];
       const uint32_t prev = (k == 0 ? left : w[k - 1]) | fold;
       const uint32_t next_dword = k == 3 ? right : w[k + 1];
       const uint32_t next = (HG_WINDOW_BYTES == 4 ? next_dword : ((w[k] >> 24) | (next_dword << 8))) | fold;
-      const bool no_prev = k == 0 && lane == 0, no_next = k == 3 && lane == 63;
-      bool ok = false;
-      if (ha) {
-        HgFilterExt e = ext[sa >> 2];
-        if (no_prev) e.pm = 0, e.pv = 0;
-        if (no_next) e.nm &= (HG_WINDOW_BYTES == 4 ? 0u : 0xFFu), e.nv &= (HG_WINDOW_BYTES == 4 ? 0u : 0xFFu);
-        ok = hg_ext_pass(e, prev, next);
-      }
-      if (hb && !ok) {
-        HgFilterExt e = ext[sb >> 2];
-        if (no_prev) e.pm = 0, e.pv = 0;
-        if (no_next) e.nm &= (HG_WINDOW_BYTES == 4 ? 0u : 0xFFu), e.nv &= (HG_WINDOW_BYTES == 4 ? 0u : 0xFFu);
-        ok = hg_ext_pass(e, prev, next);
-      }
-      if (ok) out |= 1u << k;
+      // the first lane has no left neighbour and the last lane no right neighbour inside this 1 KiB segment
+      const uint32_t pmask = (k == 0 && lane == 0) ? 0u : 0xFFFFFFFFu;
+      const uint32_t nmask = (k == 3 && lane == 63) ? (HG_WINDOW_BYTES == 4 ? 0u : 0xFFu) : 0xFFFFFFFFu;
+      const bool oka = ha && ((((prev ^ ea.pv) & ea.pm & pmask) | ((next ^ ea.nv) & ea.nm & nmask)) == 0);
+      const bool okb = hb && ((((prev ^ eb.pv) & eb.pm & pmask) | ((next ^ eb.nv) & eb.nm & nmask)) == 0);
+      if (oka || okb) out |= 1u << k;
     }
   }
   return out;
@@ -203,8 +192,10 @@ __device__ __forceinline__ void stream_tile(const uint4 *__restrict__ text16, ui
     }
     if (__ballot(any)) {
       const uint32_t l1 = Probe<LOG2>::template probe4<false>(filter, fold, wa, wb, cur);
-      const uint32_t left = __shfl_up(cur.w, 1, 64), right = __shfl_down(cur.x, 1, 64);
-      const uint32_t hits = level2_filter<LOG2>(filter, ext, fold, wa, wb, cur, left, right, lane, l1);
+      // neighbours across the lane edge: DPP wave shifts (lane i gets lane i-1 / i+1; the edge lanes' values are masked out above)
+      const uint32_t left = __builtin_amdgcn_update_dpp(0u, cur.w, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+      const uint32_t right = __builtin_amdgcn_update_dpp(0u, cur.x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+      const uint32_t hits = level2_filter<LOG2>(ext, fold, wa, wb, cur, left, right, lane, l1);
       if (__ballot(hits != 0))
         append_matches(seg, seg_cap, lds_count, (chunk0 + static_cast<uint64_t>(it) * 64u) << 4, lane, cur, tot, hits);
     }
@@ -257,7 +248,7 @@ __device__ __forceinline__ void stream_tile(const uint4 *__restrict__ text16, ui
 }  // namespace
 
 template <int LOG2>
-__global__ __launch_bounds__(WG_THREADS, 8) void hg_stream_kernel(const uint4 *__restrict__ text16, uint64_t nbytes, uint64_t ntiles,
+__global__ __launch_bounds__(WG_THREADS, 8) void hg_stream_kernel(const uint4 *__restrict__ text16, uint64_t nbytes, uint64_t tile_begin, uint64_t tile_end,
                                                                   const uint4 *__restrict__ filter16, const uint4 *__restrict__ ext16,
                                                                   uint32_t fold, uint32_t wa, uint32_t wb, HgTileSum *__restrict__ sums,
                                                                   HgCand *__restrict__ cands, uint32_t seg_cap,
@@ -283,7 +274,7 @@ __global__ __launch_bounds__(WG_THREADS, 8) void hg_stream_kernel(const uint4 *_
   const uint64_t tile_stride = static_cast<uint64_t>(gridDim.x) * WG_WAVES;
   const uint64_t full_tiles = nbytes >> HG_TILE_SHIFT;
   HgCand *seg = cands + static_cast<uint64_t>(blockIdx.x) * seg_cap;  // this workgroup's private output segment
-  for (uint64_t tile = static_cast<uint64_t>(blockIdx.x) * WG_WAVES + wave; tile < ntiles; tile += tile_stride) {
+  for (uint64_t tile = tile_begin + static_cast<uint64_t>(blockIdx.x) * WG_WAVES + wave; tile < tile_end; tile += tile_stride) {
     if (tile < full_tiles) stream_tile<LOG2, true>(text16, nbytes, tile, s_filter, ext, fold, wa, wb, sums, seg, seg_cap, &s_cand_n, lane);
     else stream_tile<LOG2, false>(text16, nbytes, tile, s_filter, ext, fold, wa, wb, sums, seg, seg_cap, &s_cand_n, lane);
   }
@@ -303,7 +294,7 @@ void hg_launch_stream(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) 
   const uint4 *x = reinterpret_cast<const uint4 *>(a.ext);
 #define HG_CASE(L)                                                                                                              \
   case L:                                                                                                                       \
-    hipLaunchKernelGGL((hg_stream_kernel<L>), dim3(grid), dim3(WG_THREADS), 0, stream, t, a.nbytes, a.ntiles, f, x, a.db.fold_mask, a.weights_a, a.weights_b, \
+    hipLaunchKernelGGL((hg_stream_kernel<L>), dim3(grid), dim3(WG_THREADS), 0, stream, t, a.nbytes, a.tile_begin, a.tile_end, f, x, a.db.fold_mask, a.weights_a, a.weights_b, \
                        a.sums, a.cands, a.cand_seg_cap, a.seg_count, a.counters);                                                                \
     break;
   switch (a.filter_log2) {
@@ -354,12 +345,12 @@ __device__ HgTileElem block_scan(HgTileElem v, HgTileElem *sh, uint64_t bs1) {
   }
   return v;
 }
-__device__ HgTileElem thread_elems(const HgTileSum *sums, uint64_t ntiles, uint64_t first, uint64_t bs1, HgTileElem *each) {
+__device__ HgTileElem thread_elems(const HgTileSum *sums, uint64_t tile_end, uint64_t first, uint64_t bs1, HgTileElem *each) {
   HgTileElem acc = identity_elem();
   for (int k = 0; k < TS_PER_THREAD; k++) {
     uint64_t t = first + k;
     HgTileElem e = identity_elem();
-    if (t < ntiles) e = hg_tile_elem(sums[t], t << HG_TILE_SHIFT);
+    if (t < tile_end) e = hg_tile_elem(sums[t], t << HG_TILE_SHIFT);
     if (each) each[k] = e;
     acc = hg_tile_combine(acc, e, bs1);
   }
@@ -367,20 +358,23 @@ __device__ HgTileElem thread_elems(const HgTileSum *sums, uint64_t ntiles, uint6
 }
 }  // namespace
 
-__global__ __launch_bounds__(TS_THREADS) void hg_tile_reduce_kernel(const HgTileSum *sums, uint64_t ntiles, uint64_t bs1, HgTileElem *agg) {
+// The three kernels work on the tile range [tile_begin, tile_end) (one chunk of the text).
+__global__ __launch_bounds__(TS_THREADS) void hg_tile_reduce_kernel(const HgTileSum *sums, uint64_t tile_begin, uint64_t tile_end, uint64_t bs1,
+                                                                    HgTileElem *agg) {
   __shared__ HgTileElem sh[TS_THREADS];
-  uint64_t first = (static_cast<uint64_t>(blockIdx.x) * TS_THREADS + threadIdx.x) * TS_PER_THREAD;
-  HgTileElem v = thread_elems(sums, ntiles, first, bs1, nullptr);
+  uint64_t first = tile_begin + (static_cast<uint64_t>(blockIdx.x) * TS_THREADS + threadIdx.x) * TS_PER_THREAD;
+  HgTileElem v = thread_elems(sums, tile_end, first, bs1, nullptr);
   v = block_scan(v, sh, bs1);
   if (threadIdx.x == TS_THREADS - 1) agg[blockIdx.x] = v;
 }
 
-// One block: exclusive scan of the block aggregates -> state at the start of each block; also the final state.
-__global__ __launch_bounds__(TS_THREADS) void hg_tile_spine_kernel(const HgTileElem *agg, uint32_t nblocks, uint64_t bs1,
-                                                                   HgTileBase init, HgTileBase *block_base, HgTileBase *final_state) {
+// One block: exclusive scan of the block aggregates -> state at the start of each block.  *state holds the state at
+// the start of the range on entry and the state at its end on exit (chunks chain through it on the device).
+__global__ __launch_bounds__(TS_THREADS) void hg_tile_spine_kernel(const HgTileElem *agg, uint32_t nblocks, uint64_t bs1, HgTileBase *block_base,
+                                                                   HgTileBase *state) {
   __shared__ HgTileElem sh[TS_THREADS];
   __shared__ HgTileBase carry;
-  if (threadIdx.x == 0) carry = init;
+  if (threadIdx.x == 0) carry = *state;
   __syncthreads();
   for (uint32_t base = 0; base < nblocks; base += TS_THREADS) {
     uint32_t i = base + threadIdx.x;
@@ -396,22 +390,22 @@ __global__ __launch_bounds__(TS_THREADS) void hg_tile_spine_kernel(const HgTileE
     if (threadIdx.x == TS_THREADS - 1) carry = hg_tile_apply(st, inc, bs1);
     __syncthreads();
   }
-  if (threadIdx.x == 0) *final_state = carry;
+  if (threadIdx.x == 0) *state = carry;
 }
 
-__global__ __launch_bounds__(TS_THREADS) void hg_tile_apply_kernel(const HgTileSum *sums, uint64_t ntiles, uint64_t bs1,
+__global__ __launch_bounds__(TS_THREADS) void hg_tile_apply_kernel(const HgTileSum *sums, uint64_t tile_begin, uint64_t tile_end, uint64_t bs1,
                                                                    const HgTileBase *block_base, HgTileBase *bases) {
   __shared__ HgTileElem sh[TS_THREADS];
-  uint64_t first = (static_cast<uint64_t>(blockIdx.x) * TS_THREADS + threadIdx.x) * TS_PER_THREAD;
+  uint64_t first = tile_begin + (static_cast<uint64_t>(blockIdx.x) * TS_THREADS + threadIdx.x) * TS_PER_THREAD;
   HgTileElem each[TS_PER_THREAD];
-  HgTileElem v = thread_elems(sums, ntiles, first, bs1, each);
+  HgTileElem v = thread_elems(sums, tile_end, first, bs1, each);
   block_scan(v, sh, bs1);
   HgTileElem excl = identity_elem();
   if (threadIdx.x > 0) excl = sh[threadIdx.x - 1];
   HgTileBase st = hg_tile_apply(block_base[blockIdx.x], excl, bs1);
   for (int k = 0; k < TS_PER_THREAD; k++) {
     uint64_t t = first + k;
-    if (t < ntiles) bases[t] = st;
+    if (t < tile_end) bases[t] = st;
     st = hg_tile_apply(st, each[k], bs1);
   }
 }
@@ -419,8 +413,8 @@ __global__ __launch_bounds__(TS_THREADS) void hg_tile_apply_kernel(const HgTileS
 // ------------------------------------------------------------------------------------------------
 // Small-buffer mode only (buffer_size - 1 < tile): lines inside a tile may split into several pieces, so the
 // per-tile count of inner pieces is recomputed by walking the tile (one thread per tile; slow path).
-__global__ __launch_bounds__(256) void hg_tile_inner_kernel(const uint8_t *text, HgTileSum *sums, uint64_t ntiles, uint64_t bs1) {
-  for (uint64_t t = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < ntiles; t += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+__global__ __launch_bounds__(256) void hg_tile_inner_kernel(const uint8_t *text, HgTileSum *sums, uint64_t tile_begin, uint64_t tile_end, uint64_t bs1) {
+  for (uint64_t t = tile_begin + static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; t < tile_end; t += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
     HgTileSum s = sums[t];
     if (s.nl_count < 2) continue;
     uint64_t base = t << HG_TILE_SHIFT;
@@ -493,6 +487,7 @@ __global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
       } else {
         const uint32_t slot = atomicAdd(&a.defer_count[shard], 1u);  // wave-aggregated by the compiler; HG_DEFER_SHARDS addresses
         if (slot < a.defer_shard_cap) dlist[slot] = HgDeferred{c.pos, pattern, c.rank};
+        else atomicMax(&a.counters[HG_CNT_DEFER_NEED], slot + 1);
       }
     });
   }
@@ -547,7 +542,7 @@ __global__ __launch_bounds__(256) void hg_always_on_kernel(HgConfirmArgs a) {
   const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n};
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
-  for (uint64_t tile = (static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6; tile < a.ntiles; tile += waves) {
+  for (uint64_t tile = a.tile_begin + ((static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6); tile < a.tile_end; tile += waves) {
     const uint64_t lo = (tile << HG_TILE_SHIFT) + lane * 256ull;
     uint64_t hi = lo + 256;
     if (hi > a.nbytes) hi = a.nbytes;

@@ -374,3 +374,31 @@ def test_face_a_hs_scan_matches_oracle(torch_cuda):
     assert product.hs_compile_multi((ctypes.c_char_p * 1)(b"(?<!a)b"), fa, ia, 1, 1, None, ctypes.byref(db), ctypes.byref(bad)) == -4
     assert bad.contents.expression == 0 and bad.contents.message
     product.hs_free_compile_error(bad)
+
+
+def test_chunked_pipeline_matches_oracle(torch_cuda, monkeypatch):
+    """Force the two-stream chunked pipeline (normally used above 512 MiB) on a 40 MiB text: chunk-crossing lines, carried
+    line numbers and double-buffered candidate segments must give the same hits as the oracle."""
+    from hypergrep_amd import benchspec, device
+
+    torch = torch_cuda
+    patterns, needles, hpm = benchspec.c3_spec(n_literals=12, n_classes=8, n_anchored=8)
+    nbytes = (40 << 20) + 4321
+    text = torch.empty(nbytes + 32, dtype=torch.uint8, device="cuda:0")
+    device.synth_device(text.data_ptr(), nbytes, seed=1234, needles=needles, hit_per_million=hpm * 3)
+    host = bytes(text[:nbytes].cpu().numpy())
+    ids = list(range(len(patterns)))
+    want, nlines = oracle_hits(host, patterns, ids=ids)
+    monkeypatch.setenv("HG_CHUNK_TILES", "1024")  # 16 MiB chunks -> 3 chunks
+    db = device.Database(patterns, ids=ids)
+    db.tune(host[: 1 << 20])
+    sc = device.Scanner(db, 0)
+    stats = sc.scan(text.data_ptr(), nbytes)
+    assert stats.n_lines == nlines
+    assert sorted(sc.hits()) == want and len(want) > 1000
+    # and again with a pattern from the always-on tier in the mix
+    pats2 = patterns + ["warn|retry"]
+    want2, _ = oracle_hits(host[: 20 << 20], pats2, ids=ids + [999])
+    sc2 = device.Scanner(device.Database(pats2, ids=ids + [999]), 0)
+    sc2.scan(text.data_ptr(), 20 << 20)
+    assert sorted(sc2.hits()) == want2
