@@ -107,7 +107,7 @@ int hg_scan_device(hg_scanner_t *scanner, const void *d_text, uint64_t nbytes, i
   result->ms_stream = o.ms_stream;
   result->ms_total = o.ms_total;
   result->reruns = o.reruns;
-  result->pad = 0;
+  result->stream_launches = o.stream_launches;
   scanner->last = *result;
   return HG_OK;
 }

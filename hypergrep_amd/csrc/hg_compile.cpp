@@ -1028,8 +1028,63 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
     for (size_t sl = 0; sl < owner.size(); sl++)
       if (owner[sl] >= 0) db.filter[sl] = entries[owner[sl]].fp;
   }
+  db.filter_wide = 0;
   if (!placed) {
-    if (err) *err = "too many distinct literal windows for the LDS filter";
+    // Wide mode for large pattern sets: every 4-byte slot holds TWO 16-bit fingerprints (cells), each window may sit
+    // in either cell of either of its two slots (bucketed cuckoo, usable up to ~85 % of the cells), and the neighbour
+    // conditions are not used (a 16-bit fingerprint hit goes straight to the verify pass).
+    for (uint32_t attempt = 0; attempt < 3 * HG_SLOT_WEIGHT_NCHOICES && !placed; attempt++) {
+      const uint32_t k = 13 + attempt / HG_SLOT_WEIGHT_NCHOICES;  // 32 / 64 / 128 KiB of LDS
+      const uint32_t wa = HG_SLOT_WEIGHT_CHOICES[attempt % HG_SLOT_WEIGHT_NCHOICES][0], wb = HG_SLOT_WEIGHT_CHOICES[attempt % HG_SLOT_WEIGHT_NCHOICES][1];
+      const size_t cells = size_t(2) << k;
+      if (values.size() * 100 > cells * 85) continue;
+      const uint32_t byte_mask = ((1u << k) - 1u) << 2;
+      struct WEntry { uint32_t sa, sb; uint16_t fp; };
+      std::vector<WEntry> entries;
+      {
+        std::vector<std::array<uint32_t, 3>> keys;
+        for (uint32_t v : values) {
+          const uint32_t a = hg_dot4(v, wa), b = hg_dot4(v, wb);
+          const uint32_t sa = hg_slot_wide(a, b, byte_mask) >> 2, sb = hg_slot_wide(b, a, byte_mask) >> 2;
+          keys.push_back({std::min(sa, sb), std::max(sa, sb), hg_hash_window(v) & 0xFFFFu});
+        }
+        std::sort(keys.begin(), keys.end());
+        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+        for (auto &key : keys) entries.push_back({key[0], key[1], static_cast<uint16_t>(key[2])});
+      }
+      std::vector<int32_t> owner(cells, -1);  // cell = slot * 2 + {0, 1}
+      uint64_t rng = 0x9E3779B97F4A7C15ull;
+      placed = true;
+      for (size_t e = 0; e < entries.size() && placed; e++) {
+        int32_t cur = static_cast<int32_t>(e);
+        bool ok = false;
+        for (int kick = 0; kick < 8000 && !ok; kick++) {
+          const uint32_t cand[4] = {entries[cur].sa * 2, entries[cur].sa * 2 + 1, entries[cur].sb * 2, entries[cur].sb * 2 + 1};
+          for (uint32_t cell : cand)
+            if (owner[cell] < 0) { owner[cell] = cur; ok = true; break; }
+          if (ok) break;
+          rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+          std::swap(cur, owner[cand[(rng >> 33) & 3]]);
+        }
+        if (!ok) placed = false;
+      }
+      if (!placed) continue;
+      db.filter.assign(size_t(1) << k, HG_FILTER_EMPTY);
+      for (size_t cell = 0; cell < cells; cell++) {
+        if (owner[cell] < 0) continue;
+        uint32_t &word = db.filter[cell >> 1];
+        const uint32_t fp = entries[owner[cell]].fp;
+        word = (cell & 1) ? ((word & 0x0000FFFFu) | (fp << 16)) : ((word & 0xFFFF0000u) | fp);
+      }
+      db.ext.assign(1, HgFilterExt{0, 0, 0, 0});
+      db.filter_log2 = k;
+      db.filter_wide = 1;
+      db.weights_a = wa;
+      db.weights_b = wb;
+    }
+  }
+  if (!placed) {
+    if (err) *err = "too many distinct literal windows for the LDS filter (more than ~55 000)";
     return -4;
   }
   return 0;

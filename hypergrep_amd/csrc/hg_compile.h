@@ -17,6 +17,7 @@ struct HgDb {
   std::vector<uint32_t> bucket_off;  // (1 << HG_HASH_BITS) + 1 offsets into windows
   std::vector<uint32_t> filter;      // 1 << filter_log2 slots holding hash C of the owning window (staged in LDS by the stream kernel)
   uint32_t filter_log2 = HG_FILTER_MIN_LOG2;
+  uint32_t filter_wide = 0;          // 1: two 16-bit fingerprints per slot, no neighbour conditions (large pattern sets)
   uint32_t weights_a = HG_SLOT_WEIGHT_CHOICES[0][0], weights_b = HG_SLOT_WEIGHT_CHOICES[0][1];
   std::vector<HgFilterExt> ext;      // per filter slot: neighbour-dword conditions (second-level check)
   std::vector<uint32_t> slow;        // indices of tier-1 (always-on) patterns

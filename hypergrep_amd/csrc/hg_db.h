@@ -101,6 +101,9 @@ HG_HD uint32_t hg_dot4(uint32_t v, uint32_t w) {
 HG_HD uint32_t hg_hash_window(uint32_t folded) { return hg_dot4(folded, HG_HASH_WEIGHTS); }
 // Byte offsets of the two candidate slots; byte_mask = (slots - 1) << 2.
 HG_HD uint32_t hg_slot(uint32_t folded, uint32_t weights, uint32_t byte_mask) { return hg_dot4(folded, weights) & byte_mask; }
+// Wide-mode slots (large pattern sets): one byte-weighted sum spans too few values for text over a small alphabet
+// (hex digits: ~9000 distinct sums), so each slot mixes the low bits of both sums, sum_x + (sum_y << 8).
+HG_HD uint32_t hg_slot_wide(uint32_t sum_x, uint32_t sum_y, uint32_t byte_mask) { return (sum_x + (sum_y << 8)) & byte_mask; }
 
 // Second-level check of a filter slot: what the dwords just before / after the window must look like
 // (folded, byte-masked) for any of the slot's windows to be part of its literal.  Conservative union.

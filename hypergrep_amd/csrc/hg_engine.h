@@ -32,6 +32,7 @@ struct HgStreamArgs {
   uint32_t *seg_count;   // candidates in each segment
   uint32_t cand_seg_cap, filter_log2;
   uint32_t weights_a, weights_b;
+  uint32_t filter_wide, pad2;
   uint32_t *counters;
 };
 
@@ -63,6 +64,7 @@ struct HgScanOutput {
   float ms_stream;       // hg_stream_kernel alone (HIP events on the launch stream)
   float ms_total;        // whole launch sequence
   uint32_t reruns;       // workspace grew and the pass was repeated this many times
+  uint32_t stream_launches;  // hg_stream_kernel launches of the (last) pass: one per pipeline chunk
 };
 
 class HgScanner {

@@ -13,7 +13,7 @@
 
 // kernels (hg_kernels.hip)
 void hg_launch_stream(const HgStreamArgs &a, uint32_t grid, hipStream_t stream);
-int hg_stream_blocks_per_cu(uint32_t filter_log2);
+int hg_stream_blocks_per_cu(uint32_t filter_log2, uint32_t filter_wide);
 __global__ void hg_tile_reduce_kernel(const HgTileSum *sums, uint64_t tile_begin, uint64_t tile_end, uint64_t bs1, HgTileElem *agg);
 __global__ void hg_tile_spine_kernel(const HgTileElem *agg, uint32_t nblocks, uint64_t bs1, HgTileBase *block_base, HgTileBase *state);
 __global__ void hg_tile_apply_kernel(const HgTileSum *sums, uint64_t tile_begin, uint64_t tile_end, uint64_t bs1, const HgTileBase *block_base,
@@ -224,8 +224,9 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
 
   uint32_t wgs = 1, confirm_blocks = 1, always_blocks = 1;
   out->ms_stream = 0;
+  out->stream_launches = ntiles ? nchunks : 0;
   if (ntiles) {
-    if (stream_wgs_per_cu_ == 0) stream_wgs_per_cu_ = hg_stream_blocks_per_cu(db_->filter_log2);
+    if (stream_wgs_per_cu_ == 0) stream_wgs_per_cu_ = hg_stream_blocks_per_cu(db_->filter_log2, db_->filter_wide);
     const uint32_t per_cu = piped ? std::max(1, stream_wgs_per_cu_ - 1) : stream_wgs_per_cu_;
     wgs = static_cast<uint32_t>(std::min<uint64_t>((std::min<uint64_t>(chunk_tiles, ntiles) + STREAM_WG_WAVES - 1) / STREAM_WG_WAVES,
                                                    std::min<uint64_t>(static_cast<uint64_t>(num_cus_) * per_cu, max_segs_)));
@@ -254,6 +255,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       sa.filter_log2 = db_->filter_log2;
       sa.weights_a = db_->weights_a;
       sa.weights_b = db_->weights_b;
+      sa.filter_wide = db_->filter_wide;
       sa.ext = static_cast<const HgFilterExt *>(d_ext_);
       sa.sums = d_sums_;
       sa.cands = cands;

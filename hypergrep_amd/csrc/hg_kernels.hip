@@ -84,7 +84,7 @@ __device__ __noinline__ void append_matches(HgCand *__restrict__ seg, uint32_t s
   }
 }
 
-template <int LOG2>
+template <int LOG2, bool WIDE>
 struct Probe {
   static constexpr uint32_t BYTE_MASK = ((1u << LOG2) - 1u) << 2;
   // First level for the lane's four dwords: a slot matches if it holds the window's hash C.
@@ -99,6 +99,15 @@ struct Probe {
     const uint32_t c2 = hg_dot4(f2, HG_HASH_WEIGHTS), c3 = hg_dot4(f3, HG_HASH_WEIGHTS);
     const uint8_t *base = reinterpret_cast<const uint8_t *>(filter);
     auto at = [&](uint32_t h) { return *reinterpret_cast<const uint32_t *>(base + (h & BYTE_MASK)); };
+    if (WIDE) {  // slots mix both sums (hg_slot_wide)
+      auto wide = [&](uint32_t x, uint32_t y) { return *reinterpret_cast<const uint32_t *>(base + hg_slot_wide(x, y, BYTE_MASK)); };
+      const uint32_t ta0 = wide(a0, b0), tb0 = wide(b0, a0), ta1 = wide(a1, b1), tb1 = wide(b1, a1);
+      const uint32_t ta2 = wide(a2, b2), tb2 = wide(b2, a2), ta3 = wide(a3, b3), tb3 = wide(b3, a3);  // two 16-bit fingerprints per slot; no per-slot detail needed (no second level in wide mode)
+      auto m = [](uint32_t t, uint32_t c) { return static_cast<uint16_t>(t) == static_cast<uint16_t>(c) || static_cast<uint16_t>(t >> 16) == static_cast<uint16_t>(c); };
+      const bool m0 = m(ta0, c0) || m(tb0, c0), m1 = m(ta1, c1) || m(tb1, c1), m2 = m(ta2, c2) || m(tb2, c2), m3 = m(ta3, c3) || m(tb3, c3);
+      if (ANY_ONLY) return (m0 || m1 || m2 || m3) ? 1u : 0u;
+      return (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u) | (m3 ? 8u : 0u);
+    }
     const uint32_t ta0 = at(a0), tb0 = at(b0), ta1 = at(a1), tb1 = at(b1), ta2 = at(a2), tb2 = at(b2), ta3 = at(a3), tb3 = at(b3);
     if (ANY_ONLY) return (ta0 == c0 || tb0 == c0 || ta1 == c1 || tb1 == c1 || ta2 == c2 || tb2 == c2 || ta3 == c3 || tb3 == c3) ? 1u : 0u;
     // bits 0..3: slot A of window k matched; bits 4..7: slot B
@@ -138,7 +147,7 @@ __device__ __forceinline__ uint32_t level2_filter(const HgFilterExt *ext, uint32
 }
 
 // One tile.  FULL: the tile lies entirely inside the text (no bounds checks on the hot path).
-template <int LOG2, bool FULL>
+template <int LOG2, bool WIDE, bool FULL>
 __device__ __forceinline__ void stream_tile(const uint4 *__restrict__ text16, uint64_t nbytes, uint64_t tile, const uint32_t *filter,
                                             const HgFilterExt *ext, uint32_t fold, uint32_t wa, uint32_t wb, HgTileSum *__restrict__ sums, HgCand *__restrict__ seg, uint32_t seg_cap,
                                             uint32_t *lds_count, uint32_t lane) {
@@ -179,7 +188,7 @@ __device__ __forceinline__ void stream_tile(const uint4 *__restrict__ text16, ui
     notnl += __popc(not_newline_bits(cur.w));
     const uint32_t c = 128u - notnl;
 
-    const bool any = Probe<LOG2>::template probe4<true>(filter, fold, wa, wb, cur) != 0;
+    const bool any = Probe<LOG2, WIDE>::template probe4<true>(filter, fold, wa, wb, cur) != 0;
 
     const uint64_t nlm = __ballot(c != 0);
     if (nlm) {
@@ -191,7 +200,12 @@ __device__ __forceinline__ void stream_tile(const uint4 *__restrict__ text16, ui
       last_lane = 63u - __builtin_clzll(nlm);
     }
     if (__ballot(any)) {
-      const uint32_t l1 = Probe<LOG2>::template probe4<false>(filter, fold, wa, wb, cur);
+      const uint32_t l1 = Probe<LOG2, WIDE>::template probe4<false>(filter, fold, wa, wb, cur);
+      if (WIDE) {  // wide mode: fingerprint hits go straight to the verify pass
+        append_matches(seg, seg_cap, lds_count, (chunk0 + static_cast<uint64_t>(it) * 64u) << 4, lane, cur, tot, l1);
+        tot += c;
+        return;
+      }
       // neighbours across the lane edge: DPP wave shifts (lane i gets lane i-1 / i+1; the edge lanes' values are masked out above)
       const uint32_t left = __builtin_amdgcn_update_dpp(0u, cur.w, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
       const uint32_t right = __builtin_amdgcn_update_dpp(0u, cur.x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
@@ -247,14 +261,14 @@ __device__ __forceinline__ void stream_tile(const uint4 *__restrict__ text16, ui
 
 }  // namespace
 
-template <int LOG2>
+template <int LOG2, bool WIDE>
 __global__ __launch_bounds__(WG_THREADS, 8) void hg_stream_kernel(const uint4 *__restrict__ text16, uint64_t nbytes, uint64_t tile_begin, uint64_t tile_end,
                                                                   const uint4 *__restrict__ filter16, const uint4 *__restrict__ ext16,
                                                                   uint32_t fold, uint32_t wa, uint32_t wb, HgTileSum *__restrict__ sums,
                                                                   HgCand *__restrict__ cands, uint32_t seg_cap,
                                                                   uint32_t *__restrict__ seg_count, uint32_t *__restrict__ counters) {
   // LDS: window hash slots (4 B each) and, while they fit, the slots' neighbour conditions (16 B each)
-  constexpr bool EXT_IN_LDS = LOG2 <= 12;
+  constexpr bool EXT_IN_LDS = LOG2 <= 12 && !WIDE;
   __shared__ __attribute__((aligned(16))) uint32_t s_filter[1u << LOG2];
   __shared__ __attribute__((aligned(16))) HgFilterExt s_ext[EXT_IN_LDS ? (1u << LOG2) : 1];
   __shared__ uint32_t s_cand_n;
@@ -275,8 +289,8 @@ __global__ __launch_bounds__(WG_THREADS, 8) void hg_stream_kernel(const uint4 *_
   const uint64_t full_tiles = nbytes >> HG_TILE_SHIFT;
   HgCand *seg = cands + static_cast<uint64_t>(blockIdx.x) * seg_cap;  // this workgroup's private output segment
   for (uint64_t tile = tile_begin + static_cast<uint64_t>(blockIdx.x) * WG_WAVES + wave; tile < tile_end; tile += tile_stride) {
-    if (tile < full_tiles) stream_tile<LOG2, true>(text16, nbytes, tile, s_filter, ext, fold, wa, wb, sums, seg, seg_cap, &s_cand_n, lane);
-    else stream_tile<LOG2, false>(text16, nbytes, tile, s_filter, ext, fold, wa, wb, sums, seg, seg_cap, &s_cand_n, lane);
+    if (tile < full_tiles) stream_tile<LOG2, WIDE, true>(text16, nbytes, tile, s_filter, ext, fold, wa, wb, sums, seg, seg_cap, &s_cand_n, lane);
+    else stream_tile<LOG2, WIDE, false>(text16, nbytes, tile, s_filter, ext, fold, wa, wb, sums, seg, seg_cap, &s_cand_n, lane);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -287,32 +301,51 @@ __global__ __launch_bounds__(WG_THREADS, 8) void hg_stream_kernel(const uint4 *_
   }
 }
 
-// Host-side launcher: picks the instantiation for the database's filter size.
-void hg_launch_stream(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
+// Host-side launcher: picks the instantiation for the database's filter size / mode.
+namespace {
+template <int L, bool W>
+void launch_one(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
   const uint4 *t = reinterpret_cast<const uint4 *>(a.text);
   const uint4 *f = reinterpret_cast<const uint4 *>(a.filter);
   const uint4 *x = reinterpret_cast<const uint4 *>(a.ext);
-#define HG_CASE(L)                                                                                                              \
-  case L:                                                                                                                       \
-    hipLaunchKernelGGL((hg_stream_kernel<L>), dim3(grid), dim3(WG_THREADS), 0, stream, t, a.nbytes, a.tile_begin, a.tile_end, f, x, a.db.fold_mask, a.weights_a, a.weights_b, \
-                       a.sums, a.cands, a.cand_seg_cap, a.seg_count, a.counters);                                                                \
-    break;
-  switch (a.filter_log2) {
-    HG_CASE(11) HG_CASE(12) HG_CASE(13) HG_CASE(14) HG_CASE(15)
-    default: break;
-  }
-#undef HG_CASE
+  hipLaunchKernelGGL((hg_stream_kernel<L, W>), dim3(grid), dim3(WG_THREADS), 0, stream, t, a.nbytes, a.tile_begin, a.tile_end, f, x, a.db.fold_mask,
+                     a.weights_a, a.weights_b, a.sums, a.cands, a.cand_seg_cap, a.seg_count, a.counters);
 }
-int hg_stream_blocks_per_cu(uint32_t filter_log2) {
+template <int L, bool W>
+int blocks_one() {
   int n = 0;
-#define HG_CASE(L) \
-  case L: (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (hg_stream_kernel<L>), WG_THREADS, 0); break;
-  switch (filter_log2) {
-    HG_CASE(11) HG_CASE(12) HG_CASE(13) HG_CASE(14) HG_CASE(15)
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (hg_stream_kernel<L, W>), WG_THREADS, 0);
+  return n > 0 ? n : 1;
+}
+}  // namespace
+void hg_launch_stream(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
+  if (a.filter_wide) {
+    switch (a.filter_log2) {
+      case 13: launch_one<13, true>(a, grid, stream); break;
+      case 14: launch_one<14, true>(a, grid, stream); break;
+      case 15: launch_one<15, true>(a, grid, stream); break;
+      default: break;
+    }
+    return;
+  }
+  switch (a.filter_log2) {
+    case 11: launch_one<11, false>(a, grid, stream); break;
+    case 12: launch_one<12, false>(a, grid, stream); break;
+    case 13: launch_one<13, false>(a, grid, stream); break;
+    case 14: launch_one<14, false>(a, grid, stream); break;
+    case 15: launch_one<15, false>(a, grid, stream); break;
     default: break;
   }
-#undef HG_CASE
-  return n > 0 ? n : 1;
+}
+int hg_stream_blocks_per_cu(uint32_t filter_log2, uint32_t filter_wide) {
+  if (filter_wide) return filter_log2 == 13 ? blocks_one<13, true>() : (filter_log2 == 14 ? blocks_one<14, true>() : blocks_one<15, true>());
+  switch (filter_log2) {
+    case 11: return blocks_one<11, false>();
+    case 12: return blocks_one<12, false>();
+    case 13: return blocks_one<13, false>();
+    case 14: return blocks_one<14, false>();
+    default: return blocks_one<15, false>();
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

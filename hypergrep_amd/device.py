@@ -25,7 +25,7 @@ class HgScanResult(ctypes.Structure):
     _fields_ = [
         ("n_hits", ctypes.c_uint64), ("n_lines", ctypes.c_uint64), ("n_candidates", ctypes.c_uint64),
         ("n_raw_hits", ctypes.c_uint64), ("d_hits", ctypes.c_void_p), ("d_aux", ctypes.c_void_p),
-        ("ms_stream", ctypes.c_float), ("ms_total", ctypes.c_float), ("reruns", ctypes.c_uint32), ("pad", ctypes.c_uint32),
+        ("ms_stream", ctypes.c_float), ("ms_total", ctypes.c_float), ("reruns", ctypes.c_uint32), ("stream_launches", ctypes.c_uint32),
     ]
 
 
@@ -112,6 +112,7 @@ class ScanStats:
     ms_stream: float
     ms_total: float
     reruns: int
+    stream_launches: int = 1
 
 
 class Scanner:
@@ -132,7 +133,7 @@ class Scanner:
         if rc != 0:
             raise DeviceError(f"hg_scan_device failed ({rc}): {lib().hg_scanner_error(self._h).decode(errors='replace')}")
         self._last = res
-        return ScanStats(res.n_hits, res.n_lines, res.n_candidates, res.n_raw_hits, res.ms_stream, res.ms_total, res.reruns)
+        return ScanStats(res.n_hits, res.n_lines, res.n_candidates, res.n_raw_hits, res.ms_stream, res.ms_total, res.reruns, res.stream_launches)
 
     @property
     def d_hits(self) -> int:

@@ -140,10 +140,10 @@ typedef struct hg_scan_result {
     uint64_t n_raw_hits;   /* reports before de-duplication */
     const hg_hit_t *d_hits;    /* DEVICE pointers, valid until the next scan on this scanner */
     const hg_hit_aux_t *d_aux;
-    float ms_stream; /* duration of the streaming kernel, HIP events on the launch stream */
+    float ms_stream; /* duration of the streaming kernel (summed over its launches), HIP events on the launch stream */
     float ms_total;  /* whole launch sequence */
     uint32_t reruns; /* passes repeated because the workspace had to grow */
-    uint32_t pad;
+    uint32_t stream_launches; /* launches of the streaming kernel in this scan (one per pipeline chunk) */
 } hg_scan_result_t;
 
 typedef struct hg_db_info {

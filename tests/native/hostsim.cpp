@@ -122,8 +122,17 @@ long hgsim_scan(void *h, const uint8_t *data, uint64_t nbytes, int buffer_size, 
       };
       // first level: window hash
       const uint32_t key0 = hg_hash_window(folded);
-      const uint32_t sla = hg_slot(folded, db->weights_a, byte_mask) >> 2, slb = hg_slot(folded, db->weights_b, byte_mask) >> 2;
-      const bool ha = db->filter[sla] == key0, hb = db->filter[slb] == key0;
+      uint32_t sla = hg_slot(folded, db->weights_a, byte_mask) >> 2, slb = hg_slot(folded, db->weights_b, byte_mask) >> 2;
+      if (db->filter_wide) {
+        const uint32_t a = hg_dot4(folded, db->weights_a), b = hg_dot4(folded, db->weights_b);
+        sla = hg_slot_wide(a, b, byte_mask) >> 2, slb = hg_slot_wide(b, a, byte_mask) >> 2;
+      }
+      bool ha = db->filter[sla] == key0, hb = db->filter[slb] == key0;
+      if (db->filter_wide) {
+        const uint32_t fp = key0 & 0xFFFFu, ta = db->filter[sla], tb = db->filter[slb];
+        ha = (ta & 0xFFFFu) == fp || (ta >> 16) == fp;
+        hb = (tb & 0xFFFFu) == fp || (tb >> 16) == fp;
+      }
       if (ha || hb) {
         bitmap_hits++;
         if (getenv("HGSIM_DUMP")) l1_hist[folded]++;
@@ -138,7 +147,7 @@ long hgsim_scan(void *h, const uint8_t *data, uint64_t nbytes, int buffer_size, 
           e.nv &= e.nm;
           return hg_ext_pass(e, pf, nf);
         };
-        if (!((ha && pass(sla)) || (hb && pass(slb)))) continue;
+        if (!db->filter_wide && !((ha && pass(sla)) || (hb && pass(slb)))) continue;
         level2_hits++;
         cands.push_back(HgCand{pos, w, rank_here});
       }

@@ -170,6 +170,19 @@ def test_many_patterns_share_windows():
     assert db.info()["nslow"] == 0
 
 
+def test_large_literal_set_uses_the_wide_filter():
+    """BASELINE config 5: 4096 literals = 16384 windows, more than the one-fingerprint-per-slot filter holds."""
+    from hypergrep_amd import benchspec, device
+
+    pats, needles, hpm = benchspec.c5_spec()
+    ids = list(range(len(pats)))
+    data = device.synth_host(96 << 10, benchspec.SEED_BASE + 5, needles, hpm)
+    want, _ = oracle_hits(data, pats, ids=ids)
+    got, stats, db = sim_hits(data, pats, ids=ids)
+    assert db.info()["nwindows"] == 4 * len(pats) and db.info()["nslow"] == 0
+    assert got == want and len(got) > 50
+
+
 def test_small_buffer_sizes_match_oracle():
     rng = random.Random(21)
     pats = ["needle_in_haystack", "x", "ab+c"]

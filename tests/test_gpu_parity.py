@@ -255,6 +255,28 @@ def test_many_literals_dense_hits_and_workspace_growth(torch_cuda):
     assert len(want) > 40000
 
 
+def test_large_literal_set_wide_filter(torch_cuda):
+    """BASELINE config 5 (4096 literals, 16384 windows): the wide LDS filter (two 16-bit fingerprints per slot)."""
+    from hypergrep_amd import benchspec, device
+
+    pats, needles, hpm = benchspec.c5_spec()
+    ids = list(range(len(pats)))
+    data = device.synth_host(192 << 10, benchspec.SEED_BASE + 5, needles, hpm)
+    want, nlines = oracle_hits(data, pats, ids=ids)
+    got, stats = gpu_scan_buffer(torch_cuda, data, pats, ids=ids)
+    assert stats.n_lines == nlines and got == want and len(want) > 100
+    # and at a size where every tile path runs (count cross-checked against the generator's own hit rate)
+    torch = torch_cuda
+    nbytes = 256 << 20
+    text = torch.empty(nbytes + 32, dtype=torch.uint8, device="cuda:0")
+    device.synth_device(text.data_ptr(), nbytes, seed=benchspec.SEED_BASE + 5, needles=needles, hit_per_million=hpm)
+    sc = device.Scanner(device.Database(pats, ids=ids), 0)
+    st = sc.scan(text.data_ptr(), nbytes)
+    head = sorted(h[:3] for h in sc.hits(limit=len(want) + 64) if h[0] < nlines - 1)  # the prefix's last line is cut short
+    assert head == [w[:3] for w in want if w[0] < nlines - 1]
+    assert abs(st.n_hits / st.n_lines - hpm / 1e6) < 0.02 * hpm / 1e6 + 1e-4
+
+
 def test_synthetic_log_device_equals_host_and_oracle(torch_cuda):
     from hypergrep_amd import benchspec, device
 
