@@ -16,10 +16,17 @@ CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIB_DIR, "libhyperscanner.so")
 OBJ = os.path.join(REPO, "build", "obj")
+# Experiment builds (tools/variant_bench.py): extra -D flags and another output path, e.g.
+#   HG_BUILD_DEFINES="-DHG_STREAM_WAVES=6" HG_BUILD_OUT=build/variants/w6.so python hypergrep_amd/build.py
+EXTRA = os.environ.get("HG_BUILD_DEFINES", "").split()
+if os.environ.get("HG_BUILD_OUT"):
+    LIB = os.path.abspath(os.environ["HG_BUILD_OUT"])
+    LIB_DIR = os.path.dirname(LIB)
+    OBJ = LIB + ".obj"
 
 HIP_SOURCES = ["hg_kernels.hip", "hg_engine.hip", "hg_capi.hip", "hg_shim.hip", "hg_hsface.hip"]
 CXX_SOURCES = ["hg_compile.cpp"]
-HEADERS = ["hg_db.h", "hg_core.h", "hg_post.h", "hg_engine.h", "hg_compile.h", "hg_synth.h"]
+HEADERS = ["hg_db.h", "hg_core.h", "hg_post.h", "hg_engine.h", "hg_compile.h", "hg_synth.h", "hg_confirm_dev.h"]
 
 
 def _hipcc() -> str:
@@ -50,7 +57,7 @@ def build(verbose: bool = False, force: bool = False) -> str:
         objs.append(obj)
         if force or _stale(obj, [path] + common_deps):
             if src.endswith(".hip"):
-                cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-c", path, "-o", obj]
+                cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall"] + EXTRA + ["-c", path, "-o", obj]
             else:
                 cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-c", path, "-o", obj]
             if verbose:

@@ -1100,6 +1100,10 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
     if (err) *err = "invalid arguments: at least one expression is required";
     return -1;
   }
+  if (n > HG_MAX_PATTERNS) {
+    if (err) *err = "too many expressions (limit 16777216)";
+    return -4;
+  }
   auto db = std::make_unique<HgDb>();
   struct Pending { std::vector<Lit> lits; bool caseless; };
   std::vector<Pending> covers(n);
@@ -1207,6 +1211,7 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
         for (size_t j = 0; j < lb.size(); j++)
           if (lb[j] == 0 || (lb[j] == '\n' && j + 1 < lb.size())) clean = false;
         p.literal_only = clean ? 1 : 0;
+        p.lit_len = clean ? static_cast<uint32_t>(lb.size()) : 0;
       }
       if (fast) db->n_confirm_mode[hg_confirm_mode(p)]++;
       if (fast) {
@@ -1235,6 +1240,7 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
       HgFactor fct{};
       fct.pattern = i;
       fct.len = static_cast<uint32_t>(l.bytes.size());
+      fct.mode = hg_confirm_mode(db->patterns[i]);
       std::memcpy(fct.lit, l.bytes.data(), fct.len);
       std::memcpy(fct.cmask, l.cmask.data(), fct.len);
       db->factors.push_back(fct);

@@ -25,6 +25,7 @@ constexpr uint32_t HG_TT_ALL = (1u << 20) - 1;
 
 constexpr uint32_t HG_MAX_NODES = 1024;  // per pattern (32 state words)
 constexpr uint32_t HG_MAX_W = HG_MAX_NODES / 32;
+constexpr uint32_t HG_MAX_PATTERNS = 1u << 24;  // pattern index and window offset share one word in the verified-occurrence records
 constexpr uint32_t HG_FACTOR_MAX = 32;   // bytes of a required literal kept for the in-stream verify
 // A window = the low HG_WINDOW_BYTES bytes of a dword-aligned text dword.  4 and 3 are supported; measured on the
 // round-1 workload a 3-byte window admits 6-byte literals to the fast tier but is hit 1.5x more often by filler text.
@@ -71,7 +72,7 @@ struct HgPattern {
   uint32_t acc_all;     // accepting nodes when `simple`
   uint32_t init_word;   // init[0] when `simple`
   uint32_t literal_only;  // the whole expression is one literal (its factor): a verified occurrence IS the match
-  uint32_t pad[1];
+  uint32_t lit_len;       // length of that literal when literal_only
 };
 static_assert(sizeof(HgPattern) == 64, "HgPattern layout");
 
@@ -79,7 +80,8 @@ static_assert(sizeof(HgPattern) == 64, "HgPattern layout");
 struct HgFactor {
   uint32_t pattern;              // index into patterns[]
   uint32_t len;                  // <= HG_FACTOR_MAX
-  uint32_t pad[2];
+  uint32_t mode;                 // confirm routine of the pattern (hg_confirm_mode), copied here so the verify pass needs no pattern load
+  uint32_t pad;
   uint8_t lit[HG_FACTOR_MAX];    // literal bytes
   uint8_t cmask[HG_FACTOR_MAX];  // 0xFF exact, 0xDF case-insensitive letter
 };

@@ -15,9 +15,9 @@ constexpr uint32_t HG_DEFER_SHARDS = 64;   // append-only lists of verified cand
 
 // A verified literal occurrence whose expression still needs its automaton: pattern may match in the line holding pos.
 struct HgDeferred {
-  uint64_t pos;
-  uint32_t pattern;
-  uint32_t rank;
+  uint64_t pos;       // the window's text offset (locates the tile and the line)
+  uint32_t pattern;   // pattern index | offset of the window inside the literal << 24
+  uint32_t rank;      // newlines between the tile start and pos
 };
 enum { HG_CNT_CANDS = 0, HG_CNT_HITS = 1, HG_CNT_CAND_NEED = 2, HG_CNT_HIT_NEED = 3, HG_CNT_DEFER_NEED = 4, HG_CNT_WORDS = 8 };
 
@@ -48,8 +48,10 @@ struct HgConfirmArgs {
   HgHitAux *aux;
   HgHit *tmp_hits;  // gridDim x hit_seg_cap block-private staging
   HgHitAux *tmp_aux;
-  HgDeferred *deferred;   // HG_DEFER_SHARDS x defer_shard_cap
-  uint32_t *defer_count;  // entries appended to each shard
+  HgDeferred *deferred;   // one list per (confirm mode present in the database, shard): list_of_mode[m] * HG_DEFER_SHARDS + shard, each defer_shard_cap entries
+  uint32_t *defer_count;  // entries appended to each list, indexed mode * HG_DEFER_SHARDS + shard
+  uint32_t list_of_mode[HG_CONFIRM_MODES];
+  uint32_t mode_present[HG_CONFIRM_MODES];
   uint32_t cand_seg_cap, hit_cap, hit_seg_cap, defer_shard_cap;
   uint32_t *counters;
 };

@@ -20,8 +20,7 @@ __global__ void hg_tile_apply_kernel(const HgTileSum *sums, uint64_t tile_begin,
                                      HgTileBase *bases);
 __global__ void hg_tile_inner_kernel(const uint8_t *text, HgTileSum *sums, uint64_t tile_begin, uint64_t tile_end, uint64_t bs1);
 __global__ void hg_verify_kernel(HgConfirmArgs a);
-__global__ void hg_confirm_kernel(HgConfirmArgs a);
-__global__ void hg_confirm_ctx_kernel(HgConfirmArgs a);
+__global__ void hg_confirm_fast_kernel(HgConfirmArgs a, uint32_t blocks_per_mode);
 __global__ void hg_confirm_generic_kernel(HgConfirmArgs a);
 __global__ void hg_always_on_kernel(HgConfirmArgs a);
 __global__ void hg_block_mark_kernel(HgConfirmArgs a, uint32_t *pattern_flags);
@@ -144,7 +143,10 @@ int HgScanner::alloc_cands(uint64_t n) {
   if (fail(hipMalloc(reinterpret_cast<void **>(&d_cands2_), n * sizeof(HgCand)), "workspace alloc (candidates)")) return HG_ERR_HIP;
   if (d_deferred_) (void)hipFree(d_deferred_);
   d_deferred_ = nullptr;
-  if (fail(hipMalloc(reinterpret_cast<void **>(&d_deferred_), n * sizeof(HgDeferred)), "workspace alloc (deferred)")) return HG_ERR_HIP;
+  // verified occurrences: one set of sharded lists per confirm mode the database uses
+  uint32_t modes = 0;
+  for (uint32_t m = 0; m < HG_CONFIRM_MODES; m++) modes += db_->n_confirm_mode[m] ? 1 : 0;
+  if (fail(hipMalloc(reinterpret_cast<void **>(&d_deferred_), std::max<uint64_t>(modes, 1) * n * sizeof(HgDeferred)), "workspace alloc (deferred)")) return HG_ERR_HIP;
   cand_cap_ = static_cast<uint32_t>(n);
   return HG_OK;
 }
@@ -187,7 +189,7 @@ int HgScanner::ensure(uint64_t nbytes) {
   }
   if (!d_seg_count_) {
     max_segs_ = static_cast<uint32_t>(num_cus_) * 16;
-    if (re(d_seg_count_, max_segs_) || re(d_seg_count2_, max_segs_) || re(d_defer_count_, HG_DEFER_SHARDS)) return HG_ERR_HIP;
+    if (re(d_seg_count_, max_segs_) || re(d_seg_count2_, max_segs_) || re(d_defer_count_, HG_CONFIRM_MODES * HG_DEFER_SHARDS)) return HG_ERR_HIP;
   }
   // one candidate / hit per KiB of text to start with; grows (and the pass repeats) on overflow
   uint64_t want = std::max<uint64_t>(nbytes / 1024, 1u << 16);
@@ -227,7 +229,11 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   out->stream_launches = ntiles ? nchunks : 0;
   if (ntiles) {
     if (stream_wgs_per_cu_ == 0) stream_wgs_per_cu_ = hg_stream_blocks_per_cu(db_->filter_log2, db_->filter_wide);
-    const uint32_t per_cu = piped ? std::max(1, stream_wgs_per_cu_ - 1) : stream_wgs_per_cu_;
+    uint32_t per_cu = piped ? std::max(1, stream_wgs_per_cu_ - 1) : stream_wgs_per_cu_;
+    if (const char *env = std::getenv("HG_STREAM_WGS_PER_CU")) {  // tuning knob: resident stream workgroups per CU
+      const long v = std::strtol(env, nullptr, 10);
+      if (v >= 1 && v <= stream_wgs_per_cu_) per_cu = static_cast<uint32_t>(v);
+    }
     wgs = static_cast<uint32_t>(std::min<uint64_t>((std::min<uint64_t>(chunk_tiles, ntiles) + STREAM_WG_WAVES - 1) / STREAM_WG_WAVES,
                                                    std::min<uint64_t>(static_cast<uint64_t>(num_cus_) * per_cu, max_segs_)));
     hipStream_t side = piped ? side_stream_ : stream;
@@ -305,16 +311,22 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
         hipLaunchKernelGGL(hg_tile_apply_kernel, dim3(nblocks), dim3(256), 0, side, d_sums_, t0, t1, bs1, d_block_base_, d_bases_);
         HG_TRY(hipGetLastError(), "tile scan launch");
         if (has_anchored) {
-          confirm_blocks = wgs * HG_CONFIRM_SPLIT;  // HG_CONFIRM_SPLIT blocks share candidate segment b
+          const uint32_t verify_blocks = wgs * HG_CONFIRM_SPLIT;  // HG_CONFIRM_SPLIT blocks share candidate segment b
+          uint32_t fast_modes = 0;
+          for (uint32_t m = 0; m < 3; m++) fast_modes += db_->n_confirm_mode[m] ? 1 : 0;
+          confirm_blocks = verify_blocks * std::max(fast_modes, 1u);  // the largest grid that stages hits
           ca.hit_seg_cap = hit_cap_ / confirm_blocks;
           ca.deferred = d_deferred_;
           ca.defer_count = d_defer_count_;
           ca.defer_shard_cap = cand_cap_ / HG_DEFER_SHARDS;
-          HG_TRY(hipMemsetAsync(d_defer_count_, 0, HG_DEFER_SHARDS * 4, side), "memset deferred counts");
-          hipLaunchKernelGGL(hg_verify_kernel, dim3(confirm_blocks), dim3(256), 0, side, ca);
-          if (db_->n_confirm_mode[1]) hipLaunchKernelGGL(hg_confirm_kernel, dim3(confirm_blocks), dim3(256), 0, side, ca);
-          if (db_->n_confirm_mode[2]) hipLaunchKernelGGL(hg_confirm_ctx_kernel, dim3(confirm_blocks), dim3(256), 0, side, ca);
-          if (db_->n_confirm_mode[3]) hipLaunchKernelGGL(hg_confirm_generic_kernel, dim3(confirm_blocks), dim3(256), 0, side, ca);
+          for (uint32_t m = 0, next = 0; m < HG_CONFIRM_MODES; m++) {
+            ca.mode_present[m] = db_->n_confirm_mode[m] ? 1 : 0;
+            ca.list_of_mode[m] = db_->n_confirm_mode[m] ? next++ : 0;
+          }
+          HG_TRY(hipMemsetAsync(d_defer_count_, 0, HG_CONFIRM_MODES * HG_DEFER_SHARDS * 4, side), "memset deferred counts");
+          hipLaunchKernelGGL(hg_verify_kernel, dim3(verify_blocks), dim3(256), 0, side, ca);
+          if (fast_modes) hipLaunchKernelGGL(hg_confirm_fast_kernel, dim3(verify_blocks * fast_modes), dim3(256), 0, side, ca, verify_blocks);
+          if (db_->n_confirm_mode[3]) hipLaunchKernelGGL(hg_confirm_generic_kernel, dim3(verify_blocks), dim3(256), 0, side, ca);
           HG_TRY(hipGetLastError(), "confirm launch");
         }
         if (!db_->slow.empty()) {

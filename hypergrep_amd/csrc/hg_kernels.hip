@@ -57,58 +57,39 @@ __device__ __forceinline__ uint32_t not_newline_bits(uint32_t w) {
   return b | w | 0x7f7f7f7fu;                                     // ... or the byte's own bit 7 is set
 }
 
-// Rare path of one iteration: newline rank of every matching dword, then one LDS atomic per wave reserves
-// slots in the workgroup's private segment of the candidate buffer (a single global counter would cap the whole
-// kernel at ~90 atomics/us: measured 4.2 ms per 4 GiB for 0.36 M appends).
-__device__ __noinline__ void append_matches(HgCand *__restrict__ seg, uint32_t seg_cap, uint32_t *lds_count, uint64_t chunk_pos, uint32_t lane,
-                                            uint4 cur, uint32_t tot, uint32_t hits) {
-  const uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
-  uint32_t cnt[4];
-#pragma unroll
-  for (int k = 0; k < 4; k++) cnt[k] = __popc(~not_newline_bits(words[k]));
-  const uint32_t c = cnt[0] + cnt[1] + cnt[2] + cnt[3];
-  uint32_t rank = wave_sum(tot) + wave_inclusive_scan(c, lane) - c;  // newlines in [tile start, this lane's chunk)
-  const uint32_t mine = __popc(hits);
-  const uint32_t incl = wave_inclusive_scan(mine, lane);
-  const uint32_t total = __shfl(incl, 63, 64);
-  uint32_t base = 0;
-  if (lane == 0) base = atomicAdd(lds_count, total);
-  uint32_t slot = __shfl(base, 0, 64) + incl - mine;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    if ((hits >> k) & 1u) {
-      if (slot < seg_cap) seg[slot] = HgCand{chunk_pos + 4u * k, words[k], rank};
-      slot++;
-    }
-    rank += cnt[k];
-  }
-}
+// LDS is addressed through explicit address-space-3 pointers so that the out-of-line drain routine also gets ds_* instructions.
+using lds_u32 = __attribute__((address_space(3))) uint32_t;
+using lds_u16 = __attribute__((address_space(3))) uint16_t;
+
+constexpr uint32_t QUEUE_CAP = 128;  // per wave: drained as soon as it holds a full batch of 64, so it never exceeds 63 + 64
 
 template <int LOG2, bool WIDE>
 struct Probe {
   static constexpr uint32_t BYTE_MASK = ((1u << LOG2) - 1u) << 2;
+  __device__ __forceinline__ static uint32_t at(const lds_u32 *filter, uint32_t byte_off) {
+    return *reinterpret_cast<const lds_u32 *>(reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(filter) + byte_off);
+  }
   // First level for the lane's four dwords: a slot matches if it holds the window's hash C.
   // ANY_ONLY: non-zero iff any of the four windows matched (hot path); else per-window, per-slot match bits.
   template <bool ANY_ONLY>
-  __device__ __forceinline__ static uint32_t probe4(const uint32_t *filter, uint32_t fold, uint32_t wa, uint32_t wb, uint4 v) {
+  __device__ __forceinline__ static uint32_t probe4(const lds_u32 *filter, uint32_t fold, uint32_t wa, uint32_t wb, uint4 v) {
     const uint32_t f0 = v.x | fold, f1 = v.y | fold, f2 = v.z | fold, f3 = v.w | fold;
     // the hashes of the four windows first (independent v_dot4), then the eight LDS reads
     const uint32_t a0 = hg_dot4(f0, wa), a1 = hg_dot4(f1, wa), a2 = hg_dot4(f2, wa), a3 = hg_dot4(f3, wa);
     const uint32_t b0 = hg_dot4(f0, wb), b1 = hg_dot4(f1, wb), b2 = hg_dot4(f2, wb), b3 = hg_dot4(f3, wb);
     const uint32_t c0 = hg_dot4(f0, HG_HASH_WEIGHTS), c1 = hg_dot4(f1, HG_HASH_WEIGHTS);
     const uint32_t c2 = hg_dot4(f2, HG_HASH_WEIGHTS), c3 = hg_dot4(f3, HG_HASH_WEIGHTS);
-    const uint8_t *base = reinterpret_cast<const uint8_t *>(filter);
-    auto at = [&](uint32_t h) { return *reinterpret_cast<const uint32_t *>(base + (h & BYTE_MASK)); };
-    if (WIDE) {  // slots mix both sums (hg_slot_wide)
-      auto wide = [&](uint32_t x, uint32_t y) { return *reinterpret_cast<const uint32_t *>(base + hg_slot_wide(x, y, BYTE_MASK)); };
+    if (WIDE) {  // slots mix both sums (hg_slot_wide); two 16-bit fingerprints per slot; no second level in wide mode
+      auto wide = [&](uint32_t x, uint32_t y) { return at(filter, hg_slot_wide(x, y, BYTE_MASK)); };
       const uint32_t ta0 = wide(a0, b0), tb0 = wide(b0, a0), ta1 = wide(a1, b1), tb1 = wide(b1, a1);
-      const uint32_t ta2 = wide(a2, b2), tb2 = wide(b2, a2), ta3 = wide(a3, b3), tb3 = wide(b3, a3);  // two 16-bit fingerprints per slot; no per-slot detail needed (no second level in wide mode)
+      const uint32_t ta2 = wide(a2, b2), tb2 = wide(b2, a2), ta3 = wide(a3, b3), tb3 = wide(b3, a3);
       auto m = [](uint32_t t, uint32_t c) { return static_cast<uint16_t>(t) == static_cast<uint16_t>(c) || static_cast<uint16_t>(t >> 16) == static_cast<uint16_t>(c); };
       const bool m0 = m(ta0, c0) || m(tb0, c0), m1 = m(ta1, c1) || m(tb1, c1), m2 = m(ta2, c2) || m(tb2, c2), m3 = m(ta3, c3) || m(tb3, c3);
       if (ANY_ONLY) return (m0 || m1 || m2 || m3) ? 1u : 0u;
       return (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u) | (m3 ? 8u : 0u);
     }
-    const uint32_t ta0 = at(a0), tb0 = at(b0), ta1 = at(a1), tb1 = at(b1), ta2 = at(a2), tb2 = at(b2), ta3 = at(a3), tb3 = at(b3);
+    const uint32_t ta0 = at(filter, a0 & BYTE_MASK), tb0 = at(filter, b0 & BYTE_MASK), ta1 = at(filter, a1 & BYTE_MASK), tb1 = at(filter, b1 & BYTE_MASK);
+    const uint32_t ta2 = at(filter, a2 & BYTE_MASK), tb2 = at(filter, b2 & BYTE_MASK), ta3 = at(filter, a3 & BYTE_MASK), tb3 = at(filter, b3 & BYTE_MASK);
     if (ANY_ONLY) return (ta0 == c0 || tb0 == c0 || ta1 == c1 || tb1 == c1 || ta2 == c2 || tb2 == c2 || ta3 == c3 || tb3 == c3) ? 1u : 0u;
     // bits 0..3: slot A of window k matched; bits 4..7: slot B
     return (ta0 == c0 ? 1u : 0u) | (ta1 == c1 ? 2u : 0u) | (ta2 == c2 ? 4u : 0u) | (ta3 == c3 ? 8u : 0u) | (tb0 == c0 ? 16u : 0u) |
@@ -116,69 +97,152 @@ struct Probe {
   }
 };
 
-// Second level, entered when some lane's first level matched: the 4 bytes before and after the window must
-// agree (byte-masked) with what the matching slot's literals have there.  `l1`: bits 0..3 = slot A of window k
-// matched, bits 4..7 = slot B.  Returns bit k set iff window k survives.
-template <int LOG2>
-__device__ __forceinline__ uint32_t level2_filter(const HgFilterExt *ext, uint32_t fold, uint32_t wa, uint32_t wb, uint4 v, uint32_t left,
-                                                  uint32_t right, uint32_t lane, uint32_t l1) {
-  constexpr uint32_t BYTE_MASK = ((1u << LOG2) - 1u) << 2;
-  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-  uint32_t out = 0;
+// Everything the out-of-line drain routine needs besides the per-tile state (wave-uniform; lives in SGPRs).
+struct StreamCtx {
+  const uint4 *text16;
+  uint64_t nbytes;
+  const lds_u32 *filter;
+  const HgFilterExt *ext;      // the slots' neighbour conditions (HBM, L2-resident)
+  lds_u16 *queue;              // this wave's queue of 16-byte chunk indices (inside the tile) whose first level matched
+  lds_u32 *cand_count;         // the workgroup's candidate counter
+  HgCand *seg;                 // the workgroup's private candidate segment
+  uint32_t seg_cap, fold, wa, wb;
+};
+
+// Chunk `g` of the text with the bytes past the end of the text zeroed.
+__device__ __forceinline__ uint4 load_chunk_checked(const uint4 *__restrict__ text16, uint64_t nbytes, uint64_t g) {
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if ((g << 4) < nbytes) {
+    v = text16[g];
+    const uint64_t byte0 = g << 4;
+    if (byte0 + 16 > nbytes) {
+      const uint32_t valid = static_cast<uint32_t>(nbytes - byte0);
+      uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const bool ha = (l1 >> k) & 1u, hb = (l1 >> (k + 4)) & 1u;
-    if (ha || hb) {
-      const uint32_t f = w[k] | fold;
-      // both conditions are fetched at once (one LDS round trip); a slot that did not match counts as failed
-      const HgFilterExt ea = ext[(hg_dot4(f, wa) & BYTE_MASK) >> 2], eb = ext[(hg_dot4(f, wb) & BYTE_MASK) >> 2];
-      const uint32_t prev = (k == 0 ? left : w[k - 1]) | fold;
-      const uint32_t next_dword = k == 3 ? right : w[k + 1];
-      const uint32_t next = (HG_WINDOW_BYTES == 4 ? next_dword : ((w[k] >> 24) | (next_dword << 8))) | fold;
-      // the first lane has no left neighbour and the last lane no right neighbour inside this 1 KiB segment
-      const uint32_t pmask = (k == 0 && lane == 0) ? 0u : 0xFFFFFFFFu;
-      const uint32_t nmask = (k == 3 && lane == 63) ? (HG_WINDOW_BYTES == 4 ? 0u : 0xFFu) : 0xFFFFFFFFu;
-      const bool oka = ha && ((((prev ^ ea.pv) & ea.pm & pmask) | ((next ^ ea.nv) & ea.nm & nmask)) == 0);
-      const bool okb = hb && ((((prev ^ eb.pv) & eb.pm & pmask) | ((next ^ eb.nv) & eb.nm & nmask)) == 0);
-      if (oka || okb) out |= 1u << k;
+      for (int k = 0; k < 4; k++) {
+        const uint32_t lo = k * 4u;
+        if (valid <= lo) w[k] = 0;
+        else if (valid < lo + 4) w[k] &= (1u << ((valid - lo) * 8)) - 1u;
+      }
+      v = make_uint4(w[0], w[1], w[2], w[3]);
     }
   }
-  return out;
+  return v;
+}
+
+// Drain of one batch of the wave's queue (the rare half of the stream pass, out of line).  The hot loop only records
+// WHICH 16-byte chunks had a first-level match; here one lane takes one such chunk, re-reads it and its two neighbouring
+// dwords (L2-resident: the tile was just streamed), repeats the first level per window, applies the second level (the
+// slot's neighbour conditions) and appends the survivors to the workgroup's candidate segment.  A survivor's line rank
+// (newlines between the tile start and its chunk) comes from the per-lane newline counts the hot loop keeps packed in
+// `cnt` (one byte per iteration): a masked byte sum per lane + one wave reduction per survivor.
+// All 64 lanes must enter (the reduction needs every lane's counts); lanes >= n have no entry.
+template <int LOG2, bool WIDE>
+__device__ __noinline__ void drain_batch(const StreamCtx cx, uint64_t tile_chunk0, uint32_t first, uint32_t n, uint32_t lane, uint32_t cnt0, uint32_t cnt1,
+                                         uint32_t cnt2, uint32_t cnt3) {
+  const bool active = lane < n;
+  uint32_t e = 0, hits = 0;
+  uint4 cur = make_uint4(0, 0, 0, 0);
+  if (active) {
+    e = cx.queue[first + lane];
+    const uint64_t g = tile_chunk0 + e;
+    cur = load_chunk_checked(cx.text16, cx.nbytes, g);
+    const uint32_t l1 = Probe<LOG2, WIDE>::template probe4<false>(cx.filter, cx.fold, cx.wa, cx.wb, cur);
+    if (WIDE) {
+      hits = l1;
+    } else if (l1) {
+      // the real neighbours (zero outside the text: a literal cannot extend past either end)
+      const uint32_t *text32 = reinterpret_cast<const uint32_t *>(cx.text16);
+      const uint32_t left = g ? text32[g * 4 - 1] : 0u;
+      uint32_t right = 0;
+      if (((g + 1) << 4) < cx.nbytes) {
+        right = text32[g * 4 + 4];
+        const uint64_t rest = cx.nbytes - ((g + 1) << 4);
+        if (rest < 4) right &= (1u << (rest * 8)) - 1u;
+      }
+      constexpr uint32_t BYTE_MASK = ((1u << LOG2) - 1u) << 2;
+      // one window per lane and trip (a chunk rarely has two first-level matches): the lanes' matches sit at different k,
+      // and a loop over k would pay one HBM round trip for the conditions per k
+      for (uint32_t todo = (l1 | (l1 >> 4)) & 15u; todo; todo &= todo - 1) {
+        const uint32_t k = __ffs(todo) - 1;
+        const uint32_t wk = k == 0 ? cur.x : (k == 1 ? cur.y : (k == 2 ? cur.z : cur.w));
+        const uint32_t wp = k == 0 ? left : (k == 1 ? cur.x : (k == 2 ? cur.y : cur.z));
+        const uint32_t wn = k == 0 ? cur.y : (k == 1 ? cur.z : (k == 2 ? cur.w : right));
+        const bool ha = (l1 >> k) & 1u, hb = (l1 >> (k + 4)) & 1u;
+        const uint32_t f = wk | cx.fold;
+        const uint32_t sa = (hg_dot4(f, cx.wa) & BYTE_MASK) >> 2, sb = (hg_dot4(f, cx.wb) & BYTE_MASK) >> 2;
+        // read from HBM / L2: rare, and keeping the table out of LDS leaves room for more resident waves
+        const HgFilterExt ea = cx.ext[sa], eb = cx.ext[sb];
+        const uint32_t prev = wp | cx.fold;
+        const uint32_t next = (HG_WINDOW_BYTES == 4 ? wn : ((wk >> 24) | (wn << 8))) | cx.fold;
+        const bool oka = ha && hg_ext_pass(ea, prev, next), okb = hb && hg_ext_pass(eb, prev, next);
+        if (oka || okb) hits |= 1u << k;
+      }
+    }
+  }
+  uint64_t pending = __ballot(hits != 0);
+  if (!pending) return;
+  // ranks: one wave reduction per surviving chunk
+  uint32_t rank = 0;
+  const uint32_t cnt[4] = {cnt0, cnt1, cnt2, cnt3};
+  for (uint64_t rest = pending; rest; rest &= rest - 1) {
+    const uint32_t src = __builtin_ctzll(rest);
+    const uint32_t es = __builtin_amdgcn_readlane(e, src);
+    const uint32_t its = es >> 6, lanes = es & 63u;  // wave-uniform
+    uint32_t x = 0;
+#pragma unroll
+    for (int gidx = 0; gidx < 4; gidx++) {
+      // bytes of iterations 4*gidx .. 4*gidx+3 that lie before iteration `its`
+      const uint32_t nb = its > 4u * gidx ? (its - 4u * gidx >= 4u ? 4u : its - 4u * gidx) : 0u;
+      const uint32_t m = nb >= 4u ? 0xFFFFFFFFu : ((1u << (8u * nb)) - 1u);
+      x = __builtin_amdgcn_udot4(cnt[gidx] & m, 0x01010101u, x, false);
+    }
+    const uint32_t own = (cnt[its >> 2] >> (8u * (its & 3u))) & 0xFFu;  // dynamic index: its is uniform, the compiler selects with s_cmp
+    if (lane < lanes) x += own;
+    const uint32_t r = wave_sum(x);
+    if (lane == src) rank = r;
+  }
+  // append: slots from ballots (no wave scan), one LDS atomic per batch
+  const uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
+  uint32_t total = 0, slot[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint64_t mk = __ballot((hits >> k) & 1u);
+    slot[k] = total + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mk >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mk), 0u));
+    total += __popcll(mk);
+  }
+  uint32_t base = 0;
+  if (lane == 0) base = __hip_atomic_fetch_add(cx.cand_count, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  base = __builtin_amdgcn_readfirstlane(base);
+  const uint64_t pos = (tile_chunk0 + e) << 4;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if ((hits >> k) & 1u) {
+      const uint32_t s = base + slot[k];
+      if (s < cx.seg_cap) cx.seg[s] = HgCand{pos + 4u * k, words[k], rank};
+    }
+    rank += __popc(~not_newline_bits(words[k]));
+  }
 }
 
 // One tile.  FULL: the tile lies entirely inside the text (no bounds checks on the hot path).
 template <int LOG2, bool WIDE, bool FULL>
-__device__ __forceinline__ void stream_tile(const uint4 *__restrict__ text16, uint64_t nbytes, uint64_t tile, const uint32_t *filter,
-                                            const HgFilterExt *ext, uint32_t fold, uint32_t wa, uint32_t wb, HgTileSum *__restrict__ sums, HgCand *__restrict__ seg, uint32_t seg_cap,
-                                            uint32_t *lds_count, uint32_t lane) {
-  const uint64_t chunk0 = tile * (HG_TILE_BYTES / 16) + lane;
-  const uint64_t nchunks = (nbytes + 15) >> 4;  // 16-byte chunks holding at least one valid byte
+__device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, HgTileSum *__restrict__ sums, uint32_t lane) {
+  const uint4 *__restrict__ text16 = cx.text16;
+  const uint64_t nbytes = cx.nbytes;
+  const uint64_t tile_chunk0 = tile * (HG_TILE_BYTES / 16);
+  const uint64_t chunk0 = tile_chunk0 + lane;
 
   auto load_chunk = [&](int it) -> uint4 {
     const uint64_t g = chunk0 + static_cast<uint64_t>(it) * 64u;
     if (FULL) return text16[g];
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (g < nchunks) {
-      v = text16[g];
-      const uint64_t byte0 = g << 4;
-      if (byte0 + 16 > nbytes) {  // zero the bytes past the end of the text
-        const uint32_t valid = static_cast<uint32_t>(nbytes - byte0);
-        uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const uint32_t lo = k * 4u;
-          if (valid <= lo) w[k] = 0;
-          else if (valid < lo + 4) w[k] &= (1u << ((valid - lo) * 8)) - 1u;
-        }
-        v = make_uint4(w[0], w[1], w[2], w[3]);
-      }
-    }
-    return v;
+    return load_chunk_checked(text16, nbytes, g);
   };
 
-  uint32_t tot = 0;                            // newlines this lane saw in earlier iterations of the tile
+  uint32_t cnt[4] = {0, 0, 0, 0};              // newlines this lane saw, one byte per iteration (<= 16 each)
   uint32_t first_it = HG_NONE32, last_it = 0;  // wave-uniform: iterations holding the first / last newline
   uint32_t first_lane = 0, last_lane = 0;
+  uint32_t qn = 0;                             // wave-uniform: entries in the wave's queue
 
   auto body = [&](int it, uint4 cur) {
     // exact newline count of this lane's 16 bytes: 128 - popcount of the "not a newline" bits
@@ -186,9 +250,18 @@ __device__ __forceinline__ void stream_tile(const uint4 *__restrict__ text16, ui
     notnl += __popc(not_newline_bits(cur.y));
     notnl += __popc(not_newline_bits(cur.z));
     notnl += __popc(not_newline_bits(cur.w));
+#if defined(HG_ABLATE) && HG_ABLATE == 2  // profiling aid: no newline counting (results are wrong)
+    const uint32_t c = cur.x == 0x0a0a0a0au ? 1u : 0u;
+#else
     const uint32_t c = 128u - notnl;
+#endif
+    cnt[it >> 2] |= c << (8 * (it & 3));
 
-    const bool any = Probe<LOG2, WIDE>::template probe4<true>(filter, fold, wa, wb, cur) != 0;
+#if defined(HG_ABLATE) && HG_ABLATE == 1  // profiling aid: no window filter (results are wrong)
+    const bool any = (cur.x ^ cur.y ^ cur.z ^ cur.w) == 0x12345678u;
+#else
+    const bool any = Probe<LOG2, WIDE>::template probe4<true>(cx.filter, cx.fold, cx.wa, cx.wb, cur) != 0;
+#endif
 
     const uint64_t nlm = __ballot(c != 0);
     if (nlm) {
@@ -199,21 +272,18 @@ __device__ __forceinline__ void stream_tile(const uint4 *__restrict__ text16, ui
       last_it = it;
       last_lane = 63u - __builtin_clzll(nlm);
     }
-    if (__ballot(any)) {
-      const uint32_t l1 = Probe<LOG2, WIDE>::template probe4<false>(filter, fold, wa, wb, cur);
-      if (WIDE) {  // wide mode: fingerprint hits go straight to the verify pass
-        append_matches(seg, seg_cap, lds_count, (chunk0 + static_cast<uint64_t>(it) * 64u) << 4, lane, cur, tot, l1);
-        tot += c;
-        return;
+    const uint64_t am = __builtin_amdgcn_ballot_w64(any);
+    if (am) {  // remember the chunks; their windows are examined in batches of 64 (drain_batch)
+      if (any) {
+        const uint32_t idx = qn + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(am >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(am), 0u));
+        cx.queue[idx] = static_cast<uint16_t>(it * 64 + lane);
       }
-      // neighbours across the lane edge: DPP wave shifts (lane i gets lane i-1 / i+1; the edge lanes' values are masked out above)
-      const uint32_t left = __builtin_amdgcn_update_dpp(0u, cur.w, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-      const uint32_t right = __builtin_amdgcn_update_dpp(0u, cur.x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
-      const uint32_t hits = level2_filter<LOG2>(ext, fold, wa, wb, cur, left, right, lane, l1);
-      if (__ballot(hits != 0))
-        append_matches(seg, seg_cap, lds_count, (chunk0 + static_cast<uint64_t>(it) * 64u) << 4, lane, cur, tot, hits);
+      qn += __popcll(am);
+      if (qn >= 64u) {
+        qn -= 64u;
+        drain_batch<LOG2, WIDE>(cx, tile_chunk0, qn, 64u, lane, cnt[0], cnt[1], cnt[2], cnt[3]);
+      }
     }
-    tot += c;
   };
 
   constexpr int DEPTH = 3;  // 16-byte loads in flight per lane
@@ -228,11 +298,16 @@ __device__ __forceinline__ void stream_tile(const uint4 *__restrict__ text16, ui
       body(it, cur);
     }
   } else {
-#pragma unroll 1
+    // the partial last tile: same body, bounds-checked loads (the packed counters need a compile-time iteration index)
+#pragma unroll
     for (int it = 0; it < ITERS; it++) body(it, load_chunk(it));
   }
+  if (qn) drain_batch<LOG2, WIDE>(cx, tile_chunk0, 0u, qn, lane, cnt[0], cnt[1], cnt[2], cnt[3]);
 
   // tile summary: exact offsets of the first / last newline (re-read two 16-byte chunks, L2-resident)
+  uint32_t tot = 0;
+#pragma unroll
+  for (int gidx = 0; gidx < 4; gidx++) tot = __builtin_amdgcn_udot4(cnt[gidx], 0x01010101u, tot, false);
   const uint32_t nl_count = wave_sum(tot);
   uint32_t first_nl = HG_NONE32, last_nl = HG_NONE32;
   if (nl_count) {
@@ -261,40 +336,48 @@ __device__ __forceinline__ void stream_tile(const uint4 *__restrict__ text16, ui
 
 }  // namespace
 
+// Register budget: HG_STREAM_WAVES resident waves per SIMD (the hot loop wants ~110 VGPRs with three 16-byte loads in flight).
+#ifndef HG_STREAM_WAVES
+#define HG_STREAM_WAVES 6
+#endif
 template <int LOG2, bool WIDE>
-__global__ __launch_bounds__(WG_THREADS, 8) void hg_stream_kernel(const uint4 *__restrict__ text16, uint64_t nbytes, uint64_t tile_begin, uint64_t tile_end,
+__global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_STREAM_WAVES, 8))) void hg_stream_kernel(const uint4 *__restrict__ text16, uint64_t nbytes, uint64_t tile_begin, uint64_t tile_end,
                                                                   const uint4 *__restrict__ filter16, const uint4 *__restrict__ ext16,
                                                                   uint32_t fold, uint32_t wa, uint32_t wb, HgTileSum *__restrict__ sums,
                                                                   HgCand *__restrict__ cands, uint32_t seg_cap,
                                                                   uint32_t *__restrict__ seg_count, uint32_t *__restrict__ counters) {
-  // LDS: window hash slots (4 B each) and, while they fit, the slots' neighbour conditions (16 B each)
-  constexpr bool EXT_IN_LDS = LOG2 <= 12 && !WIDE;
-  __shared__ __attribute__((aligned(16))) uint32_t s_filter[1u << LOG2];
-  __shared__ __attribute__((aligned(16))) HgFilterExt s_ext[EXT_IN_LDS ? (1u << LOG2) : 1];
-  __shared__ uint32_t s_cand_n;
+  // LDS, one block so that the filter starts at offset 0 (its byte offsets then fold into the ds_read instructions):
+  //   window hash slots (4 B each) | per-wave chunk queues | candidate counter
+  constexpr uint32_t FILTER_U4 = (4u << LOG2) / 16, QUEUE_U4 = WG_WAVES * QUEUE_CAP * 2 / 16;
+  __shared__ uint4 s_mem[FILTER_U4 + QUEUE_U4 + 1];
   {
-    uint4 *dst = reinterpret_cast<uint4 *>(s_filter);
-    for (uint32_t i = threadIdx.x; i < (4u << LOG2) / 16; i += WG_THREADS) dst[i] = filter16[i];
-    if (EXT_IN_LDS) {
-      uint4 *edst = reinterpret_cast<uint4 *>(s_ext);
-      for (uint32_t i = threadIdx.x; i < (1u << LOG2); i += WG_THREADS) edst[i] = ext16[i];
-    }
-    if (threadIdx.x == 0) s_cand_n = 0;
+    for (uint32_t i = threadIdx.x; i < FILTER_U4; i += WG_THREADS) s_mem[i] = filter16[i];
+    if (threadIdx.x == 0) s_mem[FILTER_U4 + QUEUE_U4] = make_uint4(0, 0, 0, 0);
   }
   __syncthreads();
-  const HgFilterExt *ext = EXT_IN_LDS ? s_ext : reinterpret_cast<const HgFilterExt *>(ext16);
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  StreamCtx cx;
+  cx.text16 = text16;
+  cx.nbytes = nbytes;
+  cx.filter = (const lds_u32 *)(&s_mem[0]);
+  cx.queue = (lds_u16 *)(&s_mem[FILTER_U4]) + wave * QUEUE_CAP;
+  cx.cand_count = (lds_u32 *)(&s_mem[FILTER_U4 + QUEUE_U4]);
+  cx.ext = reinterpret_cast<const HgFilterExt *>(ext16);
+  cx.seg = cands + static_cast<uint64_t>(blockIdx.x) * seg_cap;  // this workgroup's private output segment
+  cx.seg_cap = seg_cap;
+  cx.fold = fold;
+  cx.wa = wa;
+  cx.wb = wb;
   const uint64_t tile_stride = static_cast<uint64_t>(gridDim.x) * WG_WAVES;
   const uint64_t full_tiles = nbytes >> HG_TILE_SHIFT;
-  HgCand *seg = cands + static_cast<uint64_t>(blockIdx.x) * seg_cap;  // this workgroup's private output segment
   for (uint64_t tile = tile_begin + static_cast<uint64_t>(blockIdx.x) * WG_WAVES + wave; tile < tile_end; tile += tile_stride) {
-    if (tile < full_tiles) stream_tile<LOG2, WIDE, true>(text16, nbytes, tile, s_filter, ext, fold, wa, wb, sums, seg, seg_cap, &s_cand_n, lane);
-    else stream_tile<LOG2, WIDE, false>(text16, nbytes, tile, s_filter, ext, fold, wa, wb, sums, seg, seg_cap, &s_cand_n, lane);
+    if (tile < full_tiles) stream_tile<LOG2, WIDE, true>(cx, tile, sums, lane);
+    else stream_tile<LOG2, WIDE, false>(cx, tile, sums, lane);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const uint32_t n = s_cand_n;
+    const uint32_t n = *cx.cand_count;
     seg_count[blockIdx.x] = n < seg_cap ? n : seg_cap;
     atomicAdd(&counters[HG_CNT_CANDS], n < seg_cap ? n : seg_cap);
     if (n > seg_cap) atomicMax(&counters[HG_CNT_CAND_NEED], n);
@@ -494,45 +577,110 @@ __device__ __forceinline__ void flush_hits(const HgConfirmArgs &a, uint32_t *lds
 // One lane per window hit of the stream pass.  Candidate segment s (written by stream workgroup s) is consumed by
 // the CONFIRM_SPLIT blocks s*CONFIRM_SPLIT .. +CONFIRM_SPLIT-1, so that even a few hundred thousand candidates
 // keep every CU busy: the work is all memory latency.
-// Verify pass: one lane per window hit of the stream pass.  Candidate segment s (written by stream workgroup s) is
-// consumed by the HG_CONFIRM_SPLIT blocks s*HG_CONFIRM_SPLIT .. +HG_CONFIRM_SPLIT-1, so that even a few hundred
-// thousand candidates keep every CU busy (the work is all memory latency).  Literal-only expressions are finished
-// here; the other verified (position, pattern) pairs go to HG_DEFER_SHARDS append-only lists for the automaton passes.
+// Verify pass.  A window hit of the stream pass names a bucket of (literal, offset) pairs that contain that window; the
+// wave flattens (hit, pair) over its 64 hits (prefix sum of the bucket sizes + binary search by shuffles) so that every
+// lane compares exactly ONE literal against the text per round, with straight-line code: one window load, the factor
+// record and the text bytes as 16-byte loads (the text unaligned), no per-lane loops.  The pass is bound by the number of
+// divergent memory instructions a wave issues (each costs >= 64 address cycles), not by bytes: the per-lane bucket loop it
+// replaces issued ~700 per wave on the round-1 workload, this issues ~30.
+// Verified occurrences are appended (one atomic per wave, mode and round) to per-mode, sharded lists; every confirm
+// routine, including the literal-only one, then runs over its own list with all lanes doing the same work.
+typedef uint32_t hg_u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
+
 __global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
-  __shared__ uint32_t s_n, s_base;
-  if (threadIdx.x == 0) s_n = 0;
-  __syncthreads();
-  const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
-  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n};
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t seg = blockIdx.x / HG_CONFIRM_SPLIT, sub = blockIdx.x % HG_CONFIRM_SPLIT;
   const HgCand *cseg = a.cands + static_cast<uint64_t>(seg) * a.cand_seg_cap;
   const uint32_t n = a.seg_count[seg];
   const uint32_t shard = blockIdx.x % HG_DEFER_SHARDS;
-  HgDeferred *dlist = a.deferred + static_cast<uint64_t>(shard) * a.defer_shard_cap;
-  for (uint32_t i = sub * blockDim.x + threadIdx.x; i < n; i += HG_CONFIRM_SPLIT * blockDim.x) {
-    const HgCand c = cseg[i];
-    hgdev::verify_window(a.db, a.text, a.nbytes, c.pos, c.word, [&](uint32_t pattern, uint64_t fs, uint32_t len) {
-      const HgPattern &p = a.db.patterns[pattern];
-      if (hg_confirm_mode(p) == 0) {
-        const uint32_t id = p.id;
-        hgdev::confirm_literal(a.text, a.nbytes, a.sums, a.bases, a.bs1, c.pos, c.rank, fs, len,
-                               [&](uint64_t line_no, uint32_t to, uint64_t start, uint32_t l) { sink.push(line_no, id, to, start, l, pattern); });
-      } else {
-        const uint32_t slot = atomicAdd(&a.defer_count[shard], 1u);  // wave-aggregated by the compiler; HG_DEFER_SHARDS addresses
-        if (slot < a.defer_shard_cap) dlist[slot] = HgDeferred{c.pos, pattern, c.rank};
-        else atomicMax(&a.counters[HG_CNT_DEFER_NEED], slot + 1);
+  const uint32_t fold = a.db.fold_mask;
+  const uint64_t readable = (a.nbytes + 15) & ~15ull;  // the text buffer can be read up to here
+  for (uint32_t base = (sub * 4u + wave) * 64u; base < n; base += HG_CONFIRM_SPLIT * 256u) {  // wave-uniform
+    const uint32_t i = base + lane;
+    HgCand c{0, 0, 0};
+    uint32_t j0 = 0, cnt = 0, folded = 0;
+    if (i < n) {
+      c = cseg[i];
+      folded = (c.word | fold) & HG_WINDOW_MASK;
+      const uint32_t h = hg_hash_window(folded);
+      j0 = a.db.bucket_off[h];
+      cnt = a.db.bucket_off[h + 1] - j0;
+    }
+    const uint32_t incl = wave_inclusive_scan(cnt, lane), start = incl - cnt;
+    const uint32_t total = __shfl(incl, 63, 64);
+    const uint32_t pos_lo = static_cast<uint32_t>(c.pos), pos_hi = static_cast<uint32_t>(c.pos >> 32);
+    for (uint32_t t0 = 0; t0 < total; t0 += 64) {  // wave-uniform
+      const uint32_t t = t0 + lane;
+      // owner of item t: the last lane whose exclusive prefix is <= t
+      uint32_t owner = 0;
+#pragma unroll
+      for (uint32_t step = 32; step; step >>= 1) {
+        const uint32_t probe = owner + step;
+        const uint32_t sp = __shfl(start, probe & 63u, 64);
+        if (probe < 64u && sp <= t) owner = probe;
       }
-    });
+      const uint32_t o_start = __shfl(start, owner, 64), o_j0 = __shfl(j0, owner, 64), o_folded = __shfl(folded, owner, 64);
+      const uint32_t o_rank = __shfl(c.rank, owner, 64);
+      const uint64_t pos = (static_cast<uint64_t>(static_cast<uint32_t>(__shfl(pos_hi, owner, 64))) << 32) | static_cast<uint32_t>(__shfl(pos_lo, owner, 64));
+      bool ok = false;
+      uint32_t mode = 0, tag = 0;
+      if (t < total) {
+        const HgWindow win = a.db.windows[o_j0 + (t - o_start)];
+        if (win.value == o_folded) {
+          const uint32_t off = win.factor_off & 0xffu;
+          const HgFactor *f = &a.db.factors[win.factor_off >> 8];
+          const uint4 hdr = *reinterpret_cast<const uint4 *>(f);  // pattern, len, mode, pad
+          const uint32_t len = hdr.y;
+          if (pos >= off && pos - off + len <= a.nbytes) {
+            const uint64_t fs = pos - off;
+            const uint8_t *tp = a.text + fs;
+            uint32_t diff = 0;
+            if (fs + (len > 16 ? 32u : 16u) <= readable) {
+              const uint4 l0 = *reinterpret_cast<const uint4 *>(f->lit), m0 = *reinterpret_cast<const uint4 *>(f->cmask);
+              const hg_u32x4_unaligned x0 = *reinterpret_cast<const hg_u32x4_unaligned *>(tp);
+              diff = ((x0[0] ^ l0.x) & m0.x) | ((x0[1] ^ l0.y) & m0.y) | ((x0[2] ^ l0.z) & m0.z) | ((x0[3] ^ l0.w) & m0.w);  // cmask is zero past len
+              if (len > 16) {
+                const uint4 l1 = *reinterpret_cast<const uint4 *>(f->lit + 16), m1 = *reinterpret_cast<const uint4 *>(f->cmask + 16);
+                const hg_u32x4_unaligned x1 = *reinterpret_cast<const hg_u32x4_unaligned *>(tp + 16);
+                diff |= ((x1[0] ^ l1.x) & m1.x) | ((x1[1] ^ l1.y) & m1.y) | ((x1[2] ^ l1.z) & m1.z) | ((x1[3] ^ l1.w) & m1.w);
+              }
+            } else {  // the last bytes of the buffer: byte compares
+              for (uint32_t b = 0; b < len; b++) diff |= (tp[b] ^ f->lit[b]) & f->cmask[b];
+            }
+            if (diff == 0) {
+              ok = true;
+              mode = hdr.z;
+              tag = hdr.x | (off << 24);
+            }
+          }
+        }
+      }
+      if (!__builtin_amdgcn_ballot_w64(ok)) continue;
+#pragma unroll
+      for (uint32_t m = 0; m < HG_CONFIRM_MODES; m++) {
+        const uint64_t mm = __builtin_amdgcn_ballot_w64(ok && mode == m);
+        if (!mm) continue;
+        uint32_t slot0 = 0;
+        if (lane == 0) slot0 = atomicAdd(&a.defer_count[m * HG_DEFER_SHARDS + shard], static_cast<uint32_t>(__popcll(mm)));
+        slot0 = __builtin_amdgcn_readfirstlane(slot0);
+        if (ok && mode == m) {
+          const uint32_t slot = slot0 + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mm >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mm), 0u));
+          if (slot < a.defer_shard_cap) a.deferred[(static_cast<uint64_t>(a.list_of_mode[m]) * HG_DEFER_SHARDS + shard) * a.defer_shard_cap + slot] = HgDeferred{pos, tag, o_rank};
+          else atomicMax(&a.counters[HG_CNT_DEFER_NEED], slot + 1);
+        }
+      }
+    }
   }
-  flush_hits(a, &s_n, &s_base);
 }
 
 // Automaton passes over the deferred lists, one launch per confirm mode present in the database so that lanes of a
 // wave run the same routine and the common modes keep a small register footprint:
+//   MODE 0 literal-only expressions (the verified occurrence is the match: locate the piece, apply the NUL rules),
 //   MODE 1 context-free single-word automaton (follow table in LDS), MODE 2 <= 2 state words with boundary conditions,
 //   MODE 3 the scalar reference routine (multi-word state, all-matches mode).
+// vblock / vgrid: this block's index among the blocks working on MODE (several modes can share one launch).
 template <int MODE>
-__device__ __forceinline__ void confirm_body(const HgConfirmArgs &a) {
+__device__ __forceinline__ void confirm_body(const HgConfirmArgs &a, uint32_t vblock, uint32_t vgrid) {
   __shared__ uint32_t s_n, s_base;
   __shared__ uint32_t s_follow[MODE == 1 ? 32 * 256 : 1];
   if (threadIdx.x == 0) s_n = 0;
@@ -541,17 +689,19 @@ __device__ __forceinline__ void confirm_body(const HgConfirmArgs &a) {
   const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n};
   uint32_t *follow_lds = MODE == 1 ? s_follow + (threadIdx.x >> 6) * (32 * 64) + (threadIdx.x & 63u) : s_follow;
   // block b walks shard b % HG_DEFER_SHARDS with the blocks that share it
-  const uint32_t shard = blockIdx.x % HG_DEFER_SHARDS, peer = blockIdx.x / HG_DEFER_SHARDS, peers = (gridDim.x + HG_DEFER_SHARDS - 1 - shard) / HG_DEFER_SHARDS;
-  const HgDeferred *dlist = a.deferred + static_cast<uint64_t>(shard) * a.defer_shard_cap;
-  uint32_t n = a.defer_count[shard];
+  const uint32_t shard = vblock % HG_DEFER_SHARDS, peer = vblock / HG_DEFER_SHARDS, peers = (vgrid + HG_DEFER_SHARDS - 1 - shard) / HG_DEFER_SHARDS;
+  const HgDeferred *dlist = a.deferred + (static_cast<uint64_t>(a.list_of_mode[MODE]) * HG_DEFER_SHARDS + shard) * a.defer_shard_cap;
+  uint32_t n = a.defer_count[MODE * HG_DEFER_SHARDS + shard];
   if (n > a.defer_shard_cap) n = a.defer_shard_cap;
   for (uint32_t i = peer * blockDim.x + threadIdx.x; i < n; i += peers * blockDim.x) {
     const HgDeferred d = dlist[i];
-    const HgPattern &p = a.db.patterns[d.pattern];
-    if (hg_confirm_mode(p) != MODE) continue;
-    const uint32_t id = p.id, pattern = d.pattern;
+    const uint32_t pattern = d.pattern & (HG_MAX_PATTERNS - 1u);
+    const HgPattern &p = a.db.patterns[pattern];
+    const uint32_t id = p.id;
     auto emit = [&](uint64_t line_no, uint32_t to, uint64_t start, uint32_t len) { sink.push(line_no, id, to, start, len, pattern); };
-    if (MODE == 1) {
+    if (MODE == 0) {
+      hgdev::confirm_literal(a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, d.rank, d.pos - (d.pattern >> 24), p.lit_len, emit);
+    } else if (MODE == 1) {
       hgdev::confirm_simple(a.db, a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, p, d.rank, follow_lds, emit);
     } else if (MODE == 2) {
       if (p.nw == 1) hgdev::confirm_ctx<1>(a.db, a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, p, d.rank, emit);
@@ -562,9 +712,19 @@ __device__ __forceinline__ void confirm_body(const HgConfirmArgs &a) {
   }
   flush_hits(a, &s_n, &s_base);
 }
-__global__ __launch_bounds__(256) void hg_confirm_kernel(HgConfirmArgs a) { confirm_body<1>(a); }
-__global__ __launch_bounds__(256) void hg_confirm_ctx_kernel(HgConfirmArgs a) { confirm_body<2>(a); }
-__global__ __launch_bounds__(256) void hg_confirm_generic_kernel(HgConfirmArgs a) { confirm_body<3>(a); }
+// Modes 0..2 in ONE launch (their items are few and each item is a chain of dependent loads: run back to back the three
+// passes cost three latency tails, side by side one): blocks [k * blocks_per_mode, (k+1) * blocks_per_mode) work on the
+// k-th mode present in the database.
+__global__ __launch_bounds__(256) void hg_confirm_fast_kernel(HgConfirmArgs a, uint32_t blocks_per_mode) {
+  const uint32_t k = blockIdx.x / blocks_per_mode, vblock = blockIdx.x % blocks_per_mode;  // block-uniform
+  uint32_t mode = 0, seen = 0;
+  for (uint32_t m = 0; m < 3; m++)
+    if (a.mode_present[m] && seen++ == k) mode = m;
+  if (mode == 0) confirm_body<0>(a, vblock, blocks_per_mode);
+  else if (mode == 1) confirm_body<1>(a, vblock, blocks_per_mode);
+  else confirm_body<2>(a, vblock, blocks_per_mode);
+}
+__global__ __launch_bounds__(256) void hg_confirm_generic_kernel(HgConfirmArgs a) { confirm_body<3>(a, blockIdx.x, gridDim.x); }
 
 // Always-on tier: one wave per tile, each lane owns 256 bytes and handles the lines that START there.
 __global__ __launch_bounds__(256) void hg_always_on_kernel(HgConfirmArgs a) {
