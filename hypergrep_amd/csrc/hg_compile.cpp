@@ -928,6 +928,63 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
   for (size_t i = 1; i < db.bucket_off.size(); i++) db.bucket_off[i] += db.bucket_off[i - 1];
   if (db.windows.empty()) db.windows.push_back(HgWindow{0, 0});  // keep device arrays non-empty
 
+  // Discriminated buckets for the GPU verify pass (hg_db.h): per hash-C group the literal dword that splits it best.
+  {
+    db.disc.assign(size_t(1) << HG_HASH_BITS, 0);
+    std::vector<std::pair<uint32_t, HgWindow>> keyed2;
+    for (size_t g0 = 0; g0 < keyed.size();) {
+      size_t g1 = g0;
+      while (g1 < keyed.size() && keyed[g1].first == keyed[g0].first) g1++;
+      const uint32_t h = keyed[g0].first;
+      int best_delta = 0;
+      uint32_t best_sel = 0;
+      size_t best_distinct = 1;
+      auto key_of = [&](const HgWindow &w, int delta, uint32_t sel) {
+        const HgFactor &fct = db.factors[w.factor_off >> 8];
+        const int at = static_cast<int>(w.factor_off & 0xff) + delta;
+        uint32_t v = 0;
+        for (int b = 0; b < 4; b++)
+          if ((sel >> b) & 1u) v |= static_cast<uint32_t>(fct.lit[at + b]) << (8 * b);
+        return (v | fold) & hg_disc_bytes(sel);
+      };
+      if (g1 - g0 > 2) {
+        for (int delta = -16; delta <= 28; delta += 4) {
+          if (delta == 0) continue;
+          uint32_t sel = 15;
+          for (size_t e = g0; e < g1; e++) {
+            const HgFactor &fct = db.factors[keyed[e].second.factor_off >> 8];
+            const int at = static_cast<int>(keyed[e].second.factor_off & 0xff) + delta;
+            for (int b = 0; b < 4; b++)
+              if (at + b < 0 || at + b >= static_cast<int>(fct.len)) sel &= ~(1u << b);
+          }
+          if (!sel) continue;
+          std::vector<uint32_t> ks;
+          for (size_t e = g0; e < g1; e++) ks.push_back(key_of(keyed[e].second, delta, sel));
+          std::sort(ks.begin(), ks.end());
+          const size_t distinct = static_cast<size_t>(std::unique(ks.begin(), ks.end()) - ks.begin());
+          if (distinct > best_distinct || (distinct == best_distinct && distinct > 1 && std::abs(delta) < std::abs(best_delta))) {
+            best_distinct = distinct;
+            best_delta = delta;
+            best_sel = sel;
+          }
+        }
+      }
+      db.disc[h] = static_cast<uint16_t>((static_cast<uint32_t>(best_delta) & 0xFFu) | (best_sel << 8));
+      for (size_t e = g0; e < g1; e++)
+        keyed2.push_back({hg_disc_bucket(h, best_sel ? key_of(keyed[e].second, best_delta, best_sel) : 0u), keyed[e].second});
+      g0 = g1;
+    }
+    std::stable_sort(keyed2.begin(), keyed2.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+    db.bucket_off2.assign((1u << HG_HASH_BITS) + 1, 0);
+    db.windows2.clear();
+    for (auto &kw : keyed2) {
+      db.bucket_off2[kw.first + 1]++;
+      db.windows2.push_back(kw.second);
+    }
+    for (size_t i = 1; i < db.bucket_off2.size(); i++) db.bucket_off2[i] += db.bucket_off2[i - 1];
+    if (db.windows2.empty()) db.windows2.push_back(HgWindow{0, 0});
+  }
+
   // LDS filter: cuckoo placement of the hash of each distinct window value.  Every value owns exactly one of its
   // two slots, so a lookup that reads both slots can never miss it.
   std::vector<uint32_t> values;

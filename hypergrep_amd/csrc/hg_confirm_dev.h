@@ -20,30 +20,6 @@ __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *text, uint
   return (lo >> sh) | (p[1] << (32u - sh));
 }
 
-// hg_verify_window with dword compares.  The text buffer is readable up to nbytes rounded up to 16.
-template <typename Emit>
-__device__ __forceinline__ void verify_window(const HgDbView &db, const uint8_t *text, uint64_t nbytes, uint64_t pos, uint32_t w, Emit &&emit) {
-  const uint32_t folded = (w | db.fold_mask) & HG_WINDOW_MASK;
-  const uint32_t h = hg_hash_window(folded);
-  for (uint32_t j = db.bucket_off[h], e = db.bucket_off[h + 1]; j < e; j++) {
-    const HgWindow win = db.windows[j];
-    if (win.value != folded) continue;
-    const uint32_t off = win.factor_off & 0xff;
-    const HgFactor *f = &db.factors[win.factor_off >> 8];
-    const uint32_t len = f->len;
-    if (pos < off) continue;
-    const uint64_t start = pos - off;
-    if (start + len > nbytes) continue;
-    const uint32_t *lit = reinterpret_cast<const uint32_t *>(f->lit), *cm = reinterpret_cast<const uint32_t *>(f->cmask);
-    uint32_t diff = 0;
-    for (uint32_t b = 0; b < len; b += 4) {
-      uint32_t keep = len - b >= 4 ? 0xFFFFFFFFu : ((1u << ((len - b) * 8)) - 1u);
-      diff |= (load_u32_unaligned(text, start + b) ^ lit[b >> 2]) & cm[b >> 2] & keep;
-    }
-    if (diff == 0) emit(f->pattern, start, len);
-  }
-}
-
 __device__ __forceinline__ uint32_t byte_of(const uint4 &v, uint32_t i) {
   const uint32_t w = i < 8 ? (i < 4 ? v.x : v.y) : (i < 12 ? v.z : v.w);
   return (w >> ((i & 3u) * 8u)) & 0xFFu;

@@ -49,6 +49,9 @@ struct HgDbView {
   const HgFactor *factors;
   const HgWindow *windows;
   const uint32_t *bucket_off;
+  const uint16_t *disc;          // GPU verify pass: discriminated buckets (hg_db.h)
+  const uint32_t *bucket_off2;
+  const HgWindow *windows2;
   const uint32_t *slow;
   uint32_t npatterns, nslow, fold_mask, pad;
 };
@@ -65,6 +68,13 @@ HG_HD uint32_t hg_popc(uint32_t x) {
   return __popc(x);
 #else
   return static_cast<uint32_t>(__builtin_popcount(x));
+#endif
+}
+HG_HD uint32_t hg_clz32(uint32_t x) {  // x != 0
+#if defined(__HIP_DEVICE_COMPILE__)
+  return static_cast<uint32_t>(__clz(static_cast<int>(x)));
+#else
+  return static_cast<uint32_t>(__builtin_clz(x));
 #endif
 }
 HG_HD uint32_t hg_ctz(uint32_t x) {
@@ -92,13 +102,35 @@ HG_HD uint32_t hg_prev_ctx(uint32_t c) { return c == '\n' ? HG_PC_NL : (hg_is_wo
 
 // Bucket probe + literal verify for one window hit at absolute byte `pos` (dword aligned) holding raw
 // dword `w`.  Calls emit(pattern, literal start, literal length) for every factor whose literal really occurs around pos.
+// Range [*j0, *j1) of db.windows2 that can contain the window `folded` found at `pos`: the group's discriminator dword is
+// read from the text (hg_db.h).  Empty when a discriminator byte would lie outside the text (no literal fits there).
+HG_HD void hg_disc_range(const HgDbView &db, const uint8_t *text, uint64_t nbytes, uint64_t pos, uint32_t folded, uint32_t *j0, uint32_t *j1) {
+  const uint32_t h = hg_hash_window(folded);
+  const uint32_t d = db.disc[h];
+  const uint32_t sel = d >> 8;
+  uint32_t key = 0;
+  *j0 = *j1 = 0;
+  if (sel) {
+    const int64_t at = static_cast<int64_t>(pos) + static_cast<int8_t>(d & 0xFFu);
+    const uint32_t lo = hg_ctz(sel), hi = 31u - hg_clz32(sel);  // first / last selected byte
+    if (at + static_cast<int64_t>(lo) < 0 || static_cast<uint64_t>(at + hi) >= nbytes) return;
+    uint32_t v = 0;
+    for (uint32_t b = lo; b <= hi; b++) v |= static_cast<uint32_t>(text[at + b]) << (8 * b);
+    key = (v | db.fold_mask) & hg_disc_bytes(sel);
+  }
+  const uint32_t h2 = hg_disc_bucket(h, key);
+  *j0 = db.bucket_off2[h2];
+  *j1 = db.bucket_off2[h2 + 1];
+}
+
 template <typename Emit>
 HG_HD void hg_verify_window(const HgDbView &db, const uint8_t *text, uint64_t nbytes, uint64_t pos, uint32_t w,
                             Emit &&emit) {
   uint32_t folded = (w | db.fold_mask) & HG_WINDOW_MASK;
-  uint32_t h = hg_hash_window(folded);
-  for (uint32_t j = db.bucket_off[h], e = db.bucket_off[h + 1]; j < e; j++) {
-    HgWindow win = db.windows[j];
+  uint32_t j0, j1;
+  hg_disc_range(db, text, nbytes, pos, folded, &j0, &j1);
+  for (uint32_t j = j0; j < j1; j++) {
+    HgWindow win = db.windows2[j];
     if (win.value != folded) continue;
     uint32_t off = win.factor_off & 0xff;
     const HgFactor &f = db.factors[win.factor_off >> 8];

@@ -117,6 +117,18 @@ HG_HD bool hg_ext_pass(const HgFilterExt &e, uint32_t prev_folded, uint32_t next
   return (((prev_folded ^ e.pv) & e.pm) | ((next_folded ^ e.nv) & e.nm)) == 0;
 }
 
+// Verify-pass discriminator.  Windows are grouped by hash C; a group can be large when many literals share a window
+// ("status=5xx" alternatives, common stems).  Per group the compiler picks the dword of the literals, `delta` bytes from
+// the window, whose known bytes split the group best; the verify pass reads that dword of the text and goes straight to
+// the (usually one) literal that agrees with it.  disc[h] = (delta as int8) | byte-select bits << 8.
+constexpr uint32_t HG_DISC_WEIGHTS_1 = 0xc5a36b1du, HG_DISC_WEIGHTS_2 = 0x3b9d47e1u;
+HG_HD uint32_t hg_disc_bytes(uint32_t sel4) {
+  return ((sel4 & 1u) ? 0xFFu : 0u) | ((sel4 & 2u) ? 0xFF00u : 0u) | ((sel4 & 4u) ? 0xFF0000u : 0u) | ((sel4 & 8u) ? 0xFF000000u : 0u);
+}
+HG_HD uint32_t hg_disc_bucket(uint32_t h, uint32_t masked_dword) {
+  return (h ^ (hg_dot4(masked_dword, HG_DISC_WEIGHTS_1) + (hg_dot4(masked_dword, HG_DISC_WEIGHTS_2) << 7))) & ((1u << HG_HASH_BITS) - 1u);
+}
+
 HG_HD bool hg_is_word(uint32_t b) {
   return (b - '0' < 10u) || ((b | 0x20) - 'a' < 26u) || b == '_';
 }

@@ -84,6 +84,9 @@ int HgScanner::create(const HgDb *db, int device, HgScanner **out, std::string *
   HG_TRY(upload(&s->d_factors_, db->factors), "upload factors");
   HG_TRY(upload(&s->d_windows_, db->windows), "upload windows");
   HG_TRY(upload(&s->d_bucket_, db->bucket_off), "upload buckets");
+  HG_TRY(upload(&s->d_disc_, db->disc), "upload discriminators");
+  HG_TRY(upload(&s->d_bucket2_, db->bucket_off2), "upload buckets");
+  HG_TRY(upload(&s->d_windows2_, db->windows2), "upload windows");
   HG_TRY(upload(&s->d_filter_, db->filter), "upload filter");
   HG_TRY(upload(&s->d_ext_, db->ext), "upload filter conditions");
   HG_TRY(upload(&s->d_slow_, db->slow), "upload always-on list");
@@ -92,6 +95,9 @@ int HgScanner::create(const HgDb *db, int device, HgScanner **out, std::string *
   s->view_.factors = static_cast<const HgFactor *>(s->d_factors_);
   s->view_.windows = static_cast<const HgWindow *>(s->d_windows_);
   s->view_.bucket_off = static_cast<const uint32_t *>(s->d_bucket_);
+  s->view_.disc = static_cast<const uint16_t *>(s->d_disc_);
+  s->view_.bucket_off2 = static_cast<const uint32_t *>(s->d_bucket2_);
+  s->view_.windows2 = static_cast<const HgWindow *>(s->d_windows2_);
   s->view_.slow = static_cast<const uint32_t *>(s->d_slow_);
   s->view_.npatterns = static_cast<uint32_t>(db->patterns.size());
   s->view_.nslow = static_cast<uint32_t>(db->slow.size());
@@ -118,7 +124,7 @@ HgScanner::~HgScanner() {
   (void)hipSetDevice(device_);
   void *ptrs[] = {d_patterns_, d_pool_, d_factors_, d_windows_, d_bucket_, d_filter_, d_ext_, d_slow_, d_sums_, d_bases_, d_block_base_,
                   d_final_, d_agg_, d_cands_, d_hits_raw_, d_hits_sorted_, d_hits_out_, d_aux_raw_, d_aux_sorted_, d_aux_out_,
-                  d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, d_keep_, d_counters_, d_selected_, d_temp_, d_seg_count_, d_pflags_, d_deferred_, d_defer_count_, d_seg_count2_, d_cands2_};
+                  d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, d_keep_, d_counters_, d_selected_, d_temp_, d_seg_count_, d_pflags_, d_deferred_, d_defer_count_, d_seg_count2_, d_cands2_, d_disc_, d_bucket2_, d_windows2_};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
   if (h_counters_) (void)hipHostFree(h_counters_);
@@ -314,7 +320,11 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
           const uint32_t verify_blocks = wgs * HG_CONFIRM_SPLIT;  // HG_CONFIRM_SPLIT blocks share candidate segment b
           uint32_t fast_modes = 0;
           for (uint32_t m = 0; m < 3; m++) fast_modes += db_->n_confirm_mode[m] ? 1 : 0;
-          confirm_blocks = verify_blocks * std::max(fast_modes, 1u);  // the largest grid that stages hits
+          // few, long-lived blocks per confirm routine: next to the stream pass only ~2 of them fit on a CU at a time
+          uint32_t per_cu = 2;
+          if (const char *env = std::getenv("HG_CONFIRM_BLOCKS_PER_CU")) per_cu = static_cast<uint32_t>(std::max(1l, std::min(16l, std::strtol(env, nullptr, 10))));
+          const uint32_t mode_blocks = std::max<uint32_t>(HG_DEFER_SHARDS, static_cast<uint32_t>(num_cus_) * per_cu);
+          confirm_blocks = std::max(mode_blocks * std::max(fast_modes, 1u), verify_blocks);  // the largest grid that stages hits
           ca.hit_seg_cap = hit_cap_ / confirm_blocks;
           ca.deferred = d_deferred_;
           ca.defer_count = d_defer_count_;
@@ -325,8 +335,8 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
           }
           HG_TRY(hipMemsetAsync(d_defer_count_, 0, HG_CONFIRM_MODES * HG_DEFER_SHARDS * 4, side), "memset deferred counts");
           hipLaunchKernelGGL(hg_verify_kernel, dim3(verify_blocks), dim3(256), 0, side, ca);
-          if (fast_modes) hipLaunchKernelGGL(hg_confirm_fast_kernel, dim3(verify_blocks * fast_modes), dim3(256), 0, side, ca, verify_blocks);
-          if (db_->n_confirm_mode[3]) hipLaunchKernelGGL(hg_confirm_generic_kernel, dim3(verify_blocks), dim3(256), 0, side, ca);
+          if (fast_modes) hipLaunchKernelGGL(hg_confirm_fast_kernel, dim3(mode_blocks * fast_modes), dim3(256), 0, side, ca, mode_blocks);
+          if (db_->n_confirm_mode[3]) hipLaunchKernelGGL(hg_confirm_generic_kernel, dim3(mode_blocks), dim3(256), 0, side, ca);
           HG_TRY(hipGetLastError(), "confirm launch");
         }
         if (!db_->slow.empty()) {

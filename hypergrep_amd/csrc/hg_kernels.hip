@@ -602,9 +602,29 @@ __global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
     if (i < n) {
       c = cseg[i];
       folded = (c.word | fold) & HG_WINDOW_MASK;
+      // the group's discriminator dword of the text selects the bucket (hg_disc_range, with one aligned dword load)
       const uint32_t h = hg_hash_window(folded);
-      j0 = a.db.bucket_off[h];
-      cnt = a.db.bucket_off[h + 1] - j0;
+      const uint32_t d = a.db.disc[h];
+      const uint32_t sel = d >> 8;
+      uint32_t key = 0;
+      bool inside = true;
+      if (sel) {
+        const int64_t at = static_cast<int64_t>(c.pos) + static_cast<int8_t>(d & 0xFFu);
+        const uint32_t lo = hg_ctz(sel), hi = 31u - hg_clz32(sel);
+        inside = at + static_cast<int64_t>(lo) >= 0 && static_cast<uint64_t>(at + hi) < a.nbytes;
+        if (inside) {
+          // pos and delta are multiples of 4; at < 0 only when every selected byte is past the first three: shift in zeros
+          uint32_t v;
+          if (at >= 0) v = *reinterpret_cast<const uint32_t *>(a.text + at);
+          else v = *reinterpret_cast<const uint32_t *>(a.text) << (8u * static_cast<uint32_t>(-at));
+          key = (v | fold) & hg_disc_bytes(sel);
+        }
+      }
+      if (inside) {
+        const uint32_t h2 = hg_disc_bucket(h, key);
+        j0 = a.db.bucket_off2[h2];
+        cnt = a.db.bucket_off2[h2 + 1] - j0;
+      }
     }
     const uint32_t incl = wave_inclusive_scan(cnt, lane), start = incl - cnt;
     const uint32_t total = __shfl(incl, 63, 64);
@@ -625,7 +645,7 @@ __global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
       bool ok = false;
       uint32_t mode = 0, tag = 0;
       if (t < total) {
-        const HgWindow win = a.db.windows[o_j0 + (t - o_start)];
+        const HgWindow win = a.db.windows2[o_j0 + (t - o_start)];
         if (win.value == o_folded) {
           const uint32_t off = win.factor_off & 0xffu;
           const HgFactor *f = &a.db.factors[win.factor_off >> 8];

@@ -72,6 +72,9 @@ static HgDbView view_of(HgDb *db) {
   v.factors = db->factors.data();
   v.windows = db->windows.data();
   v.bucket_off = db->bucket_off.data();
+  v.disc = db->disc.data();
+  v.bucket_off2 = db->bucket_off2.data();
+  v.windows2 = db->windows2.data();
   v.slow = db->slow.data();
   v.npatterns = db->patterns.size();
   v.nslow = db->slow.size();
