@@ -1241,6 +1241,7 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
         for (uint32_t v : nodes_of[e.first.first]) setbit(p.follow_off + v * nw, to);
       }
       db->max_nw = std::max(db->max_nw, nw);
+      db->max_id = std::max(db->max_id, p.id);
       if (nw == 1) {  // context-free single-word automaton: the confirm kernel's fast path
         bool simple = true;
         const uint32_t full = nn == 32 ? 0xFFFFFFFFu : ((1u << nn) - 1u);

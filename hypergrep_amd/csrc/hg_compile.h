@@ -26,6 +26,7 @@ struct HgDb {
   std::vector<uint32_t> slow;        // indices of tier-1 (always-on) patterns
   uint32_t fold_mask = 0;            // 0x20202020 when any tier-0 pattern is case-insensitive
   uint32_t max_nw = 1;
+  uint32_t max_id = 0;               // largest report id (sizes the sort key)
   uint32_t n_confirm_mode[HG_CONFIRM_MODES] = {0, 0, 0, 0};  // tier-0 patterns by confirm routine (hg_confirm_mode)
   std::vector<std::string> exprs;
   bool tuned = false;

@@ -109,8 +109,8 @@ class HgScanner {
   HgCand *d_cands_ = nullptr;
   HgDeferred *d_deferred_ = nullptr;
   uint32_t *d_defer_count_ = nullptr;
-  HgHit *d_hits_raw_ = nullptr, *d_hits_sorted_ = nullptr, *d_hits_out_ = nullptr;
-  HgHitAux *d_aux_raw_ = nullptr, *d_aux_sorted_ = nullptr, *d_aux_out_ = nullptr;
+  HgHit *d_hits_raw_ = nullptr, *d_hits_out_ = nullptr;
+  HgHitAux *d_aux_raw_ = nullptr, *d_aux_out_ = nullptr;
   uint64_t *d_key_a_ = nullptr, *d_key_b_ = nullptr;
   uint32_t *d_perm_a_ = nullptr, *d_perm_b_ = nullptr;
   uint8_t *d_keep_ = nullptr;

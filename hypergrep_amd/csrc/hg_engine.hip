@@ -27,8 +27,11 @@ __global__ void hg_block_mark_kernel(HgConfirmArgs a, uint32_t *pattern_flags);
 __global__ void hg_block_scan_kernel(HgConfirmArgs a, const uint32_t *pattern_flags);
 __global__ void hg_key_kernel(const HgHit *hits, const HgHitAux *aux, const HgPattern *patterns, uint32_t n, uint64_t *key, uint32_t *idx);
 __global__ void hg_line_key_kernel(const HgHit *hits, const uint32_t *perm, uint32_t n, uint64_t *key);
-__global__ void hg_gather_kernel(const HgHit *hits, const HgHitAux *aux, const uint32_t *perm, uint32_t n, HgHit *oh, HgHitAux *oa);
-__global__ void hg_keep_kernel(const HgHit *hits, const HgHitAux *aux, const HgPattern *patterns, uint32_t n, uint8_t *keep);
+__global__ void hg_key_packed_kernel(const HgHit *hits, const HgHitAux *aux, const HgPattern *patterns, uint32_t n, uint32_t id_bits, uint32_t to_bits,
+                                     uint64_t *key, uint32_t *idx);
+__global__ void hg_keep_kernel(const HgHit *hits, const HgHitAux *aux, const uint32_t *perm, const HgPattern *patterns, uint32_t n, uint8_t *keep);
+__global__ void hg_scatter_kernel(const HgHit *hits, const HgHitAux *aux, const uint32_t *perm, const uint8_t *keep, const uint32_t *pos, uint32_t n,
+                                  HgHit *oh, HgHitAux *oa, uint32_t *count);
 
 namespace {
 constexpr int TS_BLOCK_TILES = 1024;  // must match hg_kernels.hip (256 threads x 4 tiles)
@@ -123,7 +126,7 @@ int HgScanner::create(const HgDb *db, int device, HgScanner **out, std::string *
 HgScanner::~HgScanner() {
   (void)hipSetDevice(device_);
   void *ptrs[] = {d_patterns_, d_pool_, d_factors_, d_windows_, d_bucket_, d_filter_, d_ext_, d_slow_, d_sums_, d_bases_, d_block_base_,
-                  d_final_, d_agg_, d_cands_, d_hits_raw_, d_hits_sorted_, d_hits_out_, d_aux_raw_, d_aux_sorted_, d_aux_out_,
+                  d_final_, d_agg_, d_cands_, d_hits_raw_, d_hits_out_, d_aux_raw_, d_aux_out_,
                   d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, d_keep_, d_counters_, d_selected_, d_temp_, d_seg_count_, d_pflags_, d_deferred_, d_defer_count_, d_seg_count2_, d_cands2_, d_disc_, d_bucket2_, d_windows2_};
   for (void *p : ptrs)
     if (p) (void)hipFree(p);
@@ -164,13 +167,13 @@ int HgScanner::alloc_hits(uint64_t n64) {
     ptr = nullptr;
     return fail(hipMalloc(reinterpret_cast<void **>(&ptr), std::max<size_t>(count * sizeof(*ptr), 16)), "workspace alloc (hits)");
   };
-  if (re(d_hits_raw_, n) || re(d_hits_sorted_, n) || re(d_hits_out_, n) || re(d_aux_raw_, n) || re(d_aux_sorted_, n) || re(d_aux_out_, n) ||
+  if (re(d_hits_raw_, n) || re(d_hits_out_, n) || re(d_aux_raw_, n) || re(d_aux_out_, n) ||
       re(d_key_a_, n) || re(d_key_b_, n) || re(d_perm_a_, n) || re(d_perm_b_, n) || re(d_keep_, n))
     return HG_ERR_HIP;
   hit_cap_ = n;
   size_t t1 = 0, t2 = 0;
   (void)rocprim::radix_sort_pairs(nullptr, t1, d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, n, 0, 64, hipStream_t(nullptr));
-  (void)rocprim::select(nullptr, t2, d_hits_sorted_, d_keep_, d_hits_out_, d_selected_, n, hipStream_t(nullptr));
+  (void)rocprim::exclusive_scan(nullptr, t2, d_keep_, d_perm_a_, 0u, n, rocprim::plus<uint32_t>(), hipStream_t(nullptr));
   size_t need = std::max(t1, t2) + 256;
   if (need > temp_bytes_) {
     if (d_temp_) (void)hipFree(d_temp_);
@@ -401,19 +404,29 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   if (n) {
     const HgPattern *pats = static_cast<const HgPattern *>(d_patterns_);
     uint32_t blocks = (n + 255) / 256;
-    hipLaunchKernelGGL(hg_key_kernel, dim3(blocks), dim3(256), 0, stream, d_hits_raw_, d_aux_raw_, pats, n, d_key_a_, d_perm_a_);
+    // order by (line, id, to, single-after-multi): one radix sort over exactly the bits in use when they fit in 64, else two
+    const uint32_t line_bits = bits_for(line_base + n_pieces + 1), id_bits = bits_for(static_cast<uint64_t>(db_->max_id) + 1), to_bits = bits_for(bs1 + 1);
+    const uint32_t *perm = nullptr;
+    uint32_t *pos = nullptr;
     size_t tb = temp_bytes_;
-    HG_TRY(rocprim::radix_sort_pairs(d_temp_, tb, d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, n, 0, 64, stream), "radix sort (id, to)");
-    hipLaunchKernelGGL(hg_line_key_kernel, dim3(blocks), dim3(256), 0, stream, d_hits_raw_, d_perm_b_, n, d_key_a_);
+    if (line_bits + id_bits + to_bits + 1 <= 64) {
+      hipLaunchKernelGGL(hg_key_packed_kernel, dim3(blocks), dim3(256), 0, stream, d_hits_raw_, d_aux_raw_, pats, n, id_bits, to_bits, d_key_a_, d_perm_a_);
+      HG_TRY(rocprim::radix_sort_pairs(d_temp_, tb, d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, n, 0, line_bits + id_bits + to_bits + 1, stream), "radix sort");
+      perm = d_perm_b_;
+      pos = d_perm_a_;
+    } else {
+      hipLaunchKernelGGL(hg_key_kernel, dim3(blocks), dim3(256), 0, stream, d_hits_raw_, d_aux_raw_, pats, n, d_key_a_, d_perm_a_);
+      HG_TRY(rocprim::radix_sort_pairs(d_temp_, tb, d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, n, 0, 64, stream), "radix sort (id, to)");
+      hipLaunchKernelGGL(hg_line_key_kernel, dim3(blocks), dim3(256), 0, stream, d_hits_raw_, d_perm_b_, n, d_key_a_);
+      tb = temp_bytes_;
+      HG_TRY(rocprim::radix_sort_pairs(d_temp_, tb, d_key_a_, d_key_b_, d_perm_b_, d_perm_a_, n, 0, std::min<uint32_t>(64, line_bits), stream), "radix sort (line)");
+      perm = d_perm_a_;
+      pos = d_perm_b_;
+    }
+    hipLaunchKernelGGL(hg_keep_kernel, dim3(blocks), dim3(256), 0, stream, d_hits_raw_, d_aux_raw_, perm, pats, n, d_keep_);
     tb = temp_bytes_;
-    uint32_t end_bit = std::min<uint32_t>(64, bits_for(line_base + n_pieces + 1));
-    HG_TRY(rocprim::radix_sort_pairs(d_temp_, tb, d_key_a_, d_key_b_, d_perm_b_, d_perm_a_, n, 0, end_bit, stream), "radix sort (line)");
-    hipLaunchKernelGGL(hg_gather_kernel, dim3(blocks), dim3(256), 0, stream, d_hits_raw_, d_aux_raw_, d_perm_a_, n, d_hits_sorted_, d_aux_sorted_);
-    hipLaunchKernelGGL(hg_keep_kernel, dim3(blocks), dim3(256), 0, stream, d_hits_sorted_, d_aux_sorted_, pats, n, d_keep_);
-    tb = temp_bytes_;
-    HG_TRY(rocprim::select(d_temp_, tb, d_hits_sorted_, d_keep_, d_hits_out_, d_selected_, n, stream), "select hits");
-    tb = temp_bytes_;
-    HG_TRY(rocprim::select(d_temp_, tb, d_aux_sorted_, d_keep_, d_aux_out_, d_selected_, n, stream), "select aux");
+    HG_TRY(rocprim::exclusive_scan(d_temp_, tb, d_keep_, pos, 0u, n, rocprim::plus<uint32_t>(), stream), "scan");
+    hipLaunchKernelGGL(hg_scatter_kernel, dim3(blocks), dim3(256), 0, stream, d_hits_raw_, d_aux_raw_, perm, d_keep_, pos, n, d_hits_out_, d_aux_out_, d_selected_);
     HG_TRY(hipGetLastError(), "finalize launch");
     HG_TRY(hipMemcpyAsync(h_counters_ + HG_CNT_WORDS, d_selected_, 4, hipMemcpyDeviceToHost, stream), "copy count");
   }

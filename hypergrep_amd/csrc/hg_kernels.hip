@@ -814,13 +814,27 @@ __global__ void hg_line_key_kernel(const HgHit *hits, const uint32_t *perm, uint
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) key[i] = hits[perm[i]].line_no;
 }
-__global__ void hg_gather_kernel(const HgHit *hits, const HgHitAux *aux, const uint32_t *perm, uint32_t n, HgHit *oh, HgHitAux *oa) {
+__global__ void hg_key_packed_kernel(const HgHit *hits, const HgHitAux *aux, const HgPattern *patterns, uint32_t n, uint32_t id_bits, uint32_t to_bits,
+                                     uint64_t *key, uint32_t *idx) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  oh[i] = hits[perm[i]];
-  oa[i] = aux[perm[i]];
+  key[i] = hg_sort_key_packed(hits[i], patterns[aux[i].pattern].single, id_bits, to_bits);
+  idx[i] = i;
 }
-__global__ void hg_keep_kernel(const HgHit *hits, const HgHitAux *aux, const HgPattern *patterns, uint32_t n, uint8_t *keep) {
+// SINGLEMATCH / duplicate rules on the sorted order, read through the permutation (no sorted copy of the records)
+__global__ void hg_keep_kernel(const HgHit *hits, const HgHitAux *aux, const uint32_t *perm, const HgPattern *patterns, uint32_t n, uint8_t *keep) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) keep[i] = hg_keep_hit(hits, aux, patterns, i) ? 1 : 0;
+  if (i >= n) return;
+  keep[i] = hg_keep_hit_at([&](size_t j) { return hits[perm[j]]; }, [&](size_t j) { return patterns[aux[perm[j]].pattern].single != 0; }, i) ? 1 : 0;
+}
+// pos = exclusive prefix sum of keep: the kept records go to their final places; the last thread leaves the count
+__global__ void hg_scatter_kernel(const HgHit *hits, const HgHitAux *aux, const uint32_t *perm, const uint8_t *keep, const uint32_t *pos, uint32_t n,
+                                  HgHit *oh, HgHitAux *oa, uint32_t *count) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (keep[i]) {
+    oh[pos[i]] = hits[perm[i]];
+    oa[pos[i]] = aux[perm[i]];
+  }
+  if (i == n - 1) *count = pos[i] + keep[i];
 }

@@ -46,11 +46,36 @@ HG_HD HgTileBase hg_tile_apply(const HgTileBase &st, const HgTileElem &e, uint64
 HG_HD uint64_t hg_sort_key(const HgHit &h, uint32_t single) {
   return (static_cast<uint64_t>(h.id) << 32) | (static_cast<uint64_t>(h.to) << 1) | (single ? 1u : 0u);
 }
+// The whole order in ONE 64-bit key when line, id and `to` fit: line | id | to | single, fields to_bits / id_bits wide.
+HG_HD uint64_t hg_sort_key_packed(const HgHit &h, uint32_t single, uint32_t id_bits, uint32_t to_bits) {
+  return (((h.line_no << id_bits) | h.id) << (to_bits + 1)) | (static_cast<uint64_t>(h.to) << 1) | (single ? 1u : 0u);
+}
 // Report rules per (line, id) — restated Hyperscan behaviour, see oracle/ohs.c header:
 //  * expressions with HS_FLAG_SINGLEMATCH sharing the id yield ONE report (smallest end offset);
 //  * other expressions yield every distinct end offset;
 //  * identical (id, to) reports are delivered once.
 // `i` indexes arrays sorted by (line_no, hg_sort_key).
+// hit_at(j) / single_at(j): the j-th report in that order and whether its expression has HS_FLAG_SINGLEMATCH.
+template <typename HitAt, typename SingleAt>
+HG_HD bool hg_keep_hit_at(HitAt &&hit_at, SingleAt &&single_at, size_t i) {
+  const HgHit h = hit_at(i);
+  bool single = single_at(i);
+  if (i > 0) {
+    const HgHit p = hit_at(i - 1);
+    if (p.line_no == h.line_no && p.id == h.id && p.to == h.to) {
+      bool psingle = single_at(i - 1);
+      if (!single) return false;   // twin non-single kept
+      if (!psingle) return false;  // non-single with same `to` kept: report delivered once
+    }
+  }
+  if (!single) return true;
+  for (size_t j = i; j > 0; j--) {  // first single report of this (line, id)?
+    const HgHit p = hit_at(j - 1);
+    if (p.line_no != h.line_no || p.id != h.id) break;
+    if (single_at(j - 1)) return false;
+  }
+  return true;
+}
 HG_HD bool hg_keep_hit(const HgHit *hits, const HgHitAux *aux, const HgPattern *patterns, size_t i) {
   const HgHit &h = hits[i];
   bool single = patterns[aux[i].pattern].single != 0;
