@@ -59,9 +59,8 @@ __device__ __forceinline__ uint32_t not_newline_bits(uint32_t w) {
 
 // LDS is addressed through explicit address-space-3 pointers so that the out-of-line drain routine also gets ds_* instructions.
 using lds_u32 = __attribute__((address_space(3))) uint32_t;
-using lds_u16 = __attribute__((address_space(3))) uint16_t;
 
-constexpr uint32_t QUEUE_CAP = 128;  // per wave: drained as soon as it holds a full batch of 64, so it never exceeds 63 + 64
+constexpr uint32_t QUEUE_CAP = 128;  // entries (8 B) per wave: drained as soon as it holds a full batch of 64, so it never exceeds 63 + 64
 
 template <int LOG2, bool WIDE>
 struct Probe {
@@ -103,7 +102,7 @@ struct StreamCtx {
   uint64_t nbytes;
   const lds_u32 *filter;
   const HgFilterExt *ext;      // the slots' neighbour conditions (HBM, L2-resident)
-  lds_u16 *queue;              // this wave's queue of 16-byte chunk indices (inside the tile) whose first level matched
+  lds_u32 *queue;              // this wave's queue: {chunk inside the tile | newlines of the tile before it << 10, tile} per 16-byte chunk whose first level matched
   lds_u32 *cand_count;         // the workgroup's candidate counter
   HgCand *seg;                 // the workgroup's private candidate segment
   uint32_t seg_cap, fold, wa, wb;
@@ -131,21 +130,21 @@ __device__ __forceinline__ uint4 load_chunk_checked(const uint4 *__restrict__ te
 }
 
 // Drain of one batch of the wave's queue (the rare half of the stream pass, out of line).  The hot loop only records
-// WHICH 16-byte chunks had a first-level match; here one lane takes one such chunk, re-reads it and its two neighbouring
-// dwords (L2-resident: the tile was just streamed), repeats the first level per window, applies the second level (the
-// slot's neighbour conditions) and appends the survivors to the workgroup's candidate segment.  A survivor's line rank
-// (newlines between the tile start and its chunk) comes from the per-lane newline counts the hot loop keeps packed in
-// `cnt` (one byte per iteration): a masked byte sum per lane + one wave reduction per survivor.
-// All 64 lanes must enter (the reduction needs every lane's counts); lanes >= n have no entry.
+// WHICH 16-byte chunks had a first-level match (tile, chunk inside the tile, newlines of the tile before the chunk); here
+// one lane takes one such chunk, re-reads it and its two neighbouring dwords (L2-resident: the tile was streamed moments
+// ago), repeats the first level per window, applies the second level (the slot's neighbour conditions) and appends the
+// survivors to the workgroup's candidate segment.  The queue outlives tiles, so batches are full (64 entries) except the
+// last one of the kernel.
 template <int LOG2, bool WIDE>
-__device__ __noinline__ void drain_batch(const StreamCtx cx, uint64_t tile_chunk0, uint32_t first, uint32_t n, uint32_t lane, uint32_t cnt0, uint32_t cnt1,
-                                         uint32_t cnt2, uint32_t cnt3) {
+__device__ __noinline__ void drain_batch(const StreamCtx cx, uint32_t first, uint32_t n, uint32_t lane) {
   const bool active = lane < n;
-  uint32_t e = 0, hits = 0;
+  uint32_t hits = 0, rank = 0;
+  uint64_t g = 0;
   uint4 cur = make_uint4(0, 0, 0, 0);
   if (active) {
-    e = cx.queue[first + lane];
-    const uint64_t g = tile_chunk0 + e;
+    const uint32_t e_lo = cx.queue[2 * (first + lane)], e_hi = cx.queue[2 * (first + lane) + 1];
+    g = static_cast<uint64_t>(e_hi) * (HG_TILE_BYTES / 16) + (e_lo & 1023u);
+    rank = e_lo >> 10;
     cur = load_chunk_checked(cx.text16, cx.nbytes, g);
     const uint32_t l1 = Probe<LOG2, WIDE>::template probe4<false>(cx.filter, cx.fold, cx.wa, cx.wb, cur);
     if (WIDE) {
@@ -180,41 +179,20 @@ __device__ __noinline__ void drain_batch(const StreamCtx cx, uint64_t tile_chunk
       }
     }
   }
-  uint64_t pending = __ballot(hits != 0);
-  if (!pending) return;
-  // ranks: one wave reduction per surviving chunk
-  uint32_t rank = 0;
-  const uint32_t cnt[4] = {cnt0, cnt1, cnt2, cnt3};
-  for (uint64_t rest = pending; rest; rest &= rest - 1) {
-    const uint32_t src = __builtin_ctzll(rest);
-    const uint32_t es = __builtin_amdgcn_readlane(e, src);
-    const uint32_t its = es >> 6, lanes = es & 63u;  // wave-uniform
-    uint32_t x = 0;
-#pragma unroll
-    for (int gidx = 0; gidx < 4; gidx++) {
-      // bytes of iterations 4*gidx .. 4*gidx+3 that lie before iteration `its`
-      const uint32_t nb = its > 4u * gidx ? (its - 4u * gidx >= 4u ? 4u : its - 4u * gidx) : 0u;
-      const uint32_t m = nb >= 4u ? 0xFFFFFFFFu : ((1u << (8u * nb)) - 1u);
-      x = __builtin_amdgcn_udot4(cnt[gidx] & m, 0x01010101u, x, false);
-    }
-    const uint32_t own = (cnt[its >> 2] >> (8u * (its & 3u))) & 0xFFu;  // dynamic index: its is uniform, the compiler selects with s_cmp
-    if (lane < lanes) x += own;
-    const uint32_t r = wave_sum(x);
-    if (lane == src) rank = r;
-  }
+  if (!__builtin_amdgcn_ballot_w64(hits != 0)) return;
   // append: slots from ballots (no wave scan), one LDS atomic per batch
   const uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
   uint32_t total = 0, slot[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-    const uint64_t mk = __ballot((hits >> k) & 1u);
+    const uint64_t mk = __builtin_amdgcn_ballot_w64(((hits >> k) & 1u) != 0);
     slot[k] = total + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mk >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mk), 0u));
     total += __popcll(mk);
   }
   uint32_t base = 0;
   if (lane == 0) base = __hip_atomic_fetch_add(cx.cand_count, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   base = __builtin_amdgcn_readfirstlane(base);
-  const uint64_t pos = (tile_chunk0 + e) << 4;
+  const uint64_t pos = g << 4;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     if ((hits >> k) & 1u) {
@@ -226,12 +204,12 @@ __device__ __noinline__ void drain_batch(const StreamCtx cx, uint64_t tile_chunk
 }
 
 // One tile.  FULL: the tile lies entirely inside the text (no bounds checks on the hot path).
+// qn: entries in the wave's queue (wave-uniform, carried from tile to tile).
 template <int LOG2, bool WIDE, bool FULL>
-__device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, HgTileSum *__restrict__ sums, uint32_t lane) {
+__device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, HgTileSum *__restrict__ sums, uint32_t lane, uint32_t &qn) {
   const uint4 *__restrict__ text16 = cx.text16;
   const uint64_t nbytes = cx.nbytes;
-  const uint64_t tile_chunk0 = tile * (HG_TILE_BYTES / 16);
-  const uint64_t chunk0 = tile_chunk0 + lane;
+  const uint64_t chunk0 = tile * (HG_TILE_BYTES / 16) + lane;
 
   auto load_chunk = [&](int it) -> uint4 {
     const uint64_t g = chunk0 + static_cast<uint64_t>(it) * 64u;
@@ -239,10 +217,9 @@ __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, 
     return load_chunk_checked(text16, nbytes, g);
   };
 
-  uint32_t cnt[4] = {0, 0, 0, 0};              // newlines this lane saw, one byte per iteration (<= 16 each)
+  uint32_t seen = 0;                           // wave-uniform: newlines of the tile in the iterations done so far
   uint32_t first_it = HG_NONE32, last_it = 0;  // wave-uniform: iterations holding the first / last newline
   uint32_t first_lane = 0, last_lane = 0;
-  uint32_t qn = 0;                             // wave-uniform: entries in the wave's queue
 
   auto body = [&](int it, uint4 cur) {
     // exact newline count of this lane's 16 bytes: 128 - popcount of the "not a newline" bits
@@ -255,7 +232,6 @@ __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, 
 #else
     const uint32_t c = 128u - notnl;
 #endif
-    cnt[it >> 2] |= c << (8 * (it & 3));
 
 #if defined(HG_ABLATE) && HG_ABLATE == 1  // profiling aid: no window filter (results are wrong)
     const bool any = (cur.x ^ cur.y ^ cur.z ^ cur.w) == 0x12345678u;
@@ -263,7 +239,8 @@ __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, 
     const bool any = Probe<LOG2, WIDE>::template probe4<true>(cx.filter, cx.fold, cx.wa, cx.wb, cur) != 0;
 #endif
 
-    const uint64_t nlm = __ballot(c != 0);
+    const uint64_t nlm = __builtin_amdgcn_ballot_w64(c != 0);
+    const uint64_t multi = __builtin_amdgcn_ballot_w64(c > 1);  // a 16-byte chunk with several newlines: rare in logs
     if (nlm) {
       if (first_it == HG_NONE32) {
         first_it = it;
@@ -272,18 +249,30 @@ __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, 
       last_it = it;
       last_lane = 63u - __builtin_clzll(nlm);
     }
+    // newlines of the tile before this lane's chunk, cheap while every chunk of the iteration has at most one
+    uint32_t before, total;
+    if (__builtin_expect(multi == 0, 1)) {
+      before = seen + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(nlm >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(nlm), 0u));
+      total = __popcll(nlm);
+    } else {
+      const uint32_t incl = wave_inclusive_scan(c, lane);
+      before = seen + incl - c;
+      total = __builtin_amdgcn_readlane(incl, 63);
+    }
     const uint64_t am = __builtin_amdgcn_ballot_w64(any);
     if (am) {  // remember the chunks; their windows are examined in batches of 64 (drain_batch)
       if (any) {
         const uint32_t idx = qn + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(am >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(am), 0u));
-        cx.queue[idx] = static_cast<uint16_t>(it * 64 + lane);
+        cx.queue[2 * idx] = (static_cast<uint32_t>(it) * 64u + lane) | (before << 10);
+        cx.queue[2 * idx + 1] = static_cast<uint32_t>(tile);
       }
       qn += __popcll(am);
       if (qn >= 64u) {
         qn -= 64u;
-        drain_batch<LOG2, WIDE>(cx, tile_chunk0, qn, 64u, lane, cnt[0], cnt[1], cnt[2], cnt[3]);
+        drain_batch<LOG2, WIDE>(cx, qn, 64u, lane);
       }
     }
+    seen += total;
   };
 
   constexpr int DEPTH = 3;  // 16-byte loads in flight per lane
@@ -298,17 +287,12 @@ __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, 
       body(it, cur);
     }
   } else {
-    // the partial last tile: same body, bounds-checked loads (the packed counters need a compile-time iteration index)
-#pragma unroll
+#pragma unroll 1
     for (int it = 0; it < ITERS; it++) body(it, load_chunk(it));
   }
-  if (qn) drain_batch<LOG2, WIDE>(cx, tile_chunk0, 0u, qn, lane, cnt[0], cnt[1], cnt[2], cnt[3]);
 
   // tile summary: exact offsets of the first / last newline (re-read two 16-byte chunks, L2-resident)
-  uint32_t tot = 0;
-#pragma unroll
-  for (int gidx = 0; gidx < 4; gidx++) tot = __builtin_amdgcn_udot4(cnt[gidx], 0x01010101u, tot, false);
-  const uint32_t nl_count = wave_sum(tot);
+  const uint32_t nl_count = seen;
   uint32_t first_nl = HG_NONE32, last_nl = HG_NONE32;
   if (nl_count) {
     auto chunk_masks = [&](uint32_t it_, uint32_t lane_) -> uint32_t {  // bit b set: byte b of the chunk is '\n'
@@ -348,7 +332,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_S
                                                                   uint32_t *__restrict__ seg_count, uint32_t *__restrict__ counters) {
   // LDS, one block so that the filter starts at offset 0 (its byte offsets then fold into the ds_read instructions):
   //   window hash slots (4 B each) | per-wave chunk queues | candidate counter
-  constexpr uint32_t FILTER_U4 = (4u << LOG2) / 16, QUEUE_U4 = WG_WAVES * QUEUE_CAP * 2 / 16;
+  constexpr uint32_t FILTER_U4 = (4u << LOG2) / 16, QUEUE_U4 = WG_WAVES * QUEUE_CAP * 8 / 16;
   __shared__ uint4 s_mem[FILTER_U4 + QUEUE_U4 + 1];
   {
     for (uint32_t i = threadIdx.x; i < FILTER_U4; i += WG_THREADS) s_mem[i] = filter16[i];
@@ -361,7 +345,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_S
   cx.text16 = text16;
   cx.nbytes = nbytes;
   cx.filter = (const lds_u32 *)(&s_mem[0]);
-  cx.queue = (lds_u16 *)(&s_mem[FILTER_U4]) + wave * QUEUE_CAP;
+  cx.queue = (lds_u32 *)(&s_mem[FILTER_U4]) + wave * QUEUE_CAP * 2;
   cx.cand_count = (lds_u32 *)(&s_mem[FILTER_U4 + QUEUE_U4]);
   cx.ext = reinterpret_cast<const HgFilterExt *>(ext16);
   cx.seg = cands + static_cast<uint64_t>(blockIdx.x) * seg_cap;  // this workgroup's private output segment
@@ -371,10 +355,12 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_S
   cx.wb = wb;
   const uint64_t tile_stride = static_cast<uint64_t>(gridDim.x) * WG_WAVES;
   const uint64_t full_tiles = nbytes >> HG_TILE_SHIFT;
+  uint32_t qn = 0;
   for (uint64_t tile = tile_begin + static_cast<uint64_t>(blockIdx.x) * WG_WAVES + wave; tile < tile_end; tile += tile_stride) {
-    if (tile < full_tiles) stream_tile<LOG2, WIDE, true>(cx, tile, sums, lane);
-    else stream_tile<LOG2, WIDE, false>(cx, tile, sums, lane);
+    if (tile < full_tiles) stream_tile<LOG2, WIDE, true>(cx, tile, sums, lane, qn);
+    else stream_tile<LOG2, WIDE, false>(cx, tile, sums, lane, qn);
   }
+  if (qn) drain_batch<LOG2, WIDE>(cx, 0u, qn, lane);
   __syncthreads();
   if (threadIdx.x == 0) {
     const uint32_t n = *cx.cand_count;
