@@ -21,6 +21,11 @@ struct HgDeferred {
 };
 enum { HG_CNT_CANDS = 0, HG_CNT_HITS = 1, HG_CNT_CAND_NEED = 2, HG_CNT_HIT_NEED = 3, HG_CNT_DEFER_NEED = 4, HG_CNT_WORDS = 8 };
 
+// Waves per stream workgroup (one 16 KiB tile per wave at a time); shared by the kernel and the grid sizing.
+#ifndef HG_STREAM_WG_WAVES
+#define HG_STREAM_WG_WAVES 8
+#endif
+
 struct HgStreamArgs {
   const uint8_t *text;
   uint64_t nbytes, tile_begin, tile_end;  // the launch covers tiles [tile_begin, tile_end) of the text
@@ -32,7 +37,8 @@ struct HgStreamArgs {
   uint32_t *seg_count;   // candidates in each segment
   uint32_t cand_seg_cap, filter_log2;
   uint32_t weights_a, weights_b;
-  uint32_t filter_wide, pad2;
+  uint32_t filter_wide;
+  uint32_t span;  // tiles per workgroup when each owns a consecutive range, 0 = round-robin (hg_stream_kernel)
   uint32_t *counters;
 };
 

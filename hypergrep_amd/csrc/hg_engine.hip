@@ -35,7 +35,7 @@ __global__ void hg_scatter_kernel(const HgHit *hits, const HgHitAux *aux, const 
 
 namespace {
 constexpr int TS_BLOCK_TILES = 1024;  // must match hg_kernels.hip (256 threads x 4 tiles)
-constexpr int STREAM_WG_WAVES = 8;  // must match hg_kernels.hip
+constexpr int STREAM_WG_WAVES = HG_STREAM_WG_WAVES;
 
 template <typename T>
 hipError_t upload(void **dst, const std::vector<T> &src) {
@@ -271,6 +271,12 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       sa.weights_a = db_->weights_a;
       sa.weights_b = db_->weights_b;
       sa.filter_wide = db_->filter_wide;
+      // every workgroup streams its own consecutive range of tiles: same HBM rate as dealing tiles round-robin (measured),
+      // and the verify / confirm passes then find neighbouring lines in neighbouring lanes (confirm 1.8 -> 1.5 ms per 32 GiB)
+      sa.span = static_cast<uint32_t>(((t1 - t0 + wgs - 1) / wgs + STREAM_WG_WAVES - 1) / STREAM_WG_WAVES * STREAM_WG_WAVES);
+      if (const char *env = std::getenv("HG_STREAM_ROUND_ROBIN")) {
+        if (std::atoi(env)) sa.span = 0;
+      }
       sa.ext = static_cast<const HgFilterExt *>(d_ext_);
       sa.sums = d_sums_;
       sa.cands = cands;
@@ -321,8 +327,9 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
         HG_TRY(hipGetLastError(), "tile scan launch");
         if (has_anchored) {
           const uint32_t verify_blocks = wgs * HG_CONFIRM_SPLIT;  // HG_CONFIRM_SPLIT blocks share candidate segment b
-          uint32_t fast_modes = 0;
-          for (uint32_t m = 0; m < 3; m++) fast_modes += db_->n_confirm_mode[m] ? 1 : 0;
+          uint32_t fast_modes = 0, mode_mask = 0xF;
+          if (const char *env = std::getenv("HG_DEBUG_CONFIRM_MODES")) mode_mask = static_cast<uint32_t>(std::strtoul(env, nullptr, 0));  // profiling aid: results are incomplete
+          for (uint32_t m = 0; m < 3; m++) fast_modes += (db_->n_confirm_mode[m] && ((mode_mask >> m) & 1u)) ? 1 : 0;
           // few, long-lived blocks per confirm routine: next to the stream pass only ~2 of them fit on a CU at a time
           uint32_t per_cu = 2;
           if (const char *env = std::getenv("HG_CONFIRM_BLOCKS_PER_CU")) per_cu = static_cast<uint32_t>(std::max(1l, std::min(16l, std::strtol(env, nullptr, 10))));
@@ -333,7 +340,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
           ca.defer_count = d_defer_count_;
           ca.defer_shard_cap = cand_cap_ / HG_DEFER_SHARDS;
           for (uint32_t m = 0, next = 0; m < HG_CONFIRM_MODES; m++) {
-            ca.mode_present[m] = db_->n_confirm_mode[m] ? 1 : 0;
+            ca.mode_present[m] = (db_->n_confirm_mode[m] && ((mode_mask >> m) & 1u)) ? 1 : 0;
             ca.list_of_mode[m] = db_->n_confirm_mode[m] ? next++ : 0;
           }
           HG_TRY(hipMemsetAsync(d_defer_count_, 0, HG_CONFIRM_MODES * HG_DEFER_SHARDS * 4, side), "memset deferred counts");

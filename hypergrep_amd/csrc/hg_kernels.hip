@@ -21,7 +21,7 @@
 
 namespace {
 
-constexpr int WG_WAVES = 8;
+constexpr int WG_WAVES = HG_STREAM_WG_WAVES;
 constexpr int WG_THREADS = WG_WAVES * 64;
 constexpr int ITERS = HG_TILE_BYTES / 1024;  // 1 KiB per wave-iteration
 
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_S
                                                                   const uint4 *__restrict__ filter16, const uint4 *__restrict__ ext16,
                                                                   uint32_t fold, uint32_t wa, uint32_t wb, HgTileSum *__restrict__ sums,
                                                                   HgCand *__restrict__ cands, uint32_t seg_cap,
-                                                                  uint32_t *__restrict__ seg_count, uint32_t *__restrict__ counters) {
+                                                                  uint32_t *__restrict__ seg_count, uint32_t *__restrict__ counters, uint32_t span) {
   // LDS, one block so that the filter starts at offset 0 (its byte offsets then fold into the ds_read instructions):
   //   window hash slots (4 B each) | per-wave chunk queues | candidate counter
   constexpr uint32_t FILTER_U4 = (4u << LOG2) / 16, QUEUE_U4 = WG_WAVES * QUEUE_CAP * 8 / 16;
@@ -353,10 +353,20 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_S
   cx.fold = fold;
   cx.wa = wa;
   cx.wb = wb;
-  const uint64_t tile_stride = static_cast<uint64_t>(gridDim.x) * WG_WAVES;
   const uint64_t full_tiles = nbytes >> HG_TILE_SHIFT;
+  // Tile order.  span == 0: tiles are dealt round-robin over all waves of the grid (the chip streams one contiguous window).
+  // span > 0: workgroup b owns the `span` consecutive tiles from tile_begin + b * span, so that the candidates of a segment
+  // are consecutive in the text (the verify / confirm passes then touch neighbouring lines from neighbouring lanes).
+  uint64_t tile_first = tile_begin + static_cast<uint64_t>(blockIdx.x) * WG_WAVES + wave, tile_stride = static_cast<uint64_t>(gridDim.x) * WG_WAVES;
+  uint64_t tile_last = tile_end;
+  if (span) {
+    tile_first = tile_begin + static_cast<uint64_t>(blockIdx.x) * span + wave;
+    tile_stride = WG_WAVES;
+    tile_last = tile_begin + (static_cast<uint64_t>(blockIdx.x) + 1) * span;
+    if (tile_last > tile_end) tile_last = tile_end;
+  }
   uint32_t qn = 0;
-  for (uint64_t tile = tile_begin + static_cast<uint64_t>(blockIdx.x) * WG_WAVES + wave; tile < tile_end; tile += tile_stride) {
+  for (uint64_t tile = tile_first; tile < tile_last; tile += tile_stride) {
     if (tile < full_tiles) stream_tile<LOG2, WIDE, true>(cx, tile, sums, lane, qn);
     else stream_tile<LOG2, WIDE, false>(cx, tile, sums, lane, qn);
   }
@@ -378,7 +388,7 @@ void launch_one(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
   const uint4 *f = reinterpret_cast<const uint4 *>(a.filter);
   const uint4 *x = reinterpret_cast<const uint4 *>(a.ext);
   hipLaunchKernelGGL((hg_stream_kernel<L, W>), dim3(grid), dim3(WG_THREADS), 0, stream, t, a.nbytes, a.tile_begin, a.tile_end, f, x, a.db.fold_mask,
-                     a.weights_a, a.weights_b, a.sums, a.cands, a.cand_seg_cap, a.seg_count, a.counters);
+                     a.weights_a, a.weights_b, a.sums, a.cands, a.cand_seg_cap, a.seg_count, a.counters, a.span);
 }
 template <int L, bool W>
 int blocks_one() {
