@@ -31,17 +31,141 @@ __device__ __forceinline__ uint32_t eq_mask16(const uint4 &v, uint32_t c4) {
   return pack(m0) | (pack(m1) << 4) | (pack(m2) << 8) | (pack(m3) << 12);
 }
 
+// Walks over the line in aligned 16-byte chunks, FOUR loads in flight per step: a walk is a chain of dependent memory
+// round trips (each decides whether the next one is needed), and a log line is a handful of chunks, so four at a time
+// turn most walks into one round trip.  visit(chunk address, chunk) returns true to stop.
+template <typename Visit>
+__device__ __forceinline__ void walk_back4(const uint8_t *text, uint64_t chunk, uint64_t lowest_chunk, Visit &&visit) {
+  for (;;) {
+    uint4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint64_t c = chunk >= lowest_chunk + 16u * j ? chunk - 16u * j : lowest_chunk;  // clamped: never below the walk's floor
+      v[j] = *reinterpret_cast<const uint4 *>(text + c);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (chunk < lowest_chunk + 16u * j) return;
+      if (visit(chunk - 16u * j, v[j])) return;
+    }
+    if (chunk < lowest_chunk + 64u) return;
+    chunk -= 64u;
+  }
+}
+// forward over [chunk, end): `end` <= the readable size of the buffer (nbytes rounded up to 16)
+template <typename Visit>
+__device__ __forceinline__ void walk_fwd4(const uint8_t *text, uint64_t chunk, uint64_t end, Visit &&visit) {
+  for (; chunk < end; chunk += 64u) {
+    uint4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint64_t c = chunk + 16u * j < end ? chunk + 16u * j : chunk;
+      v[j] = *reinterpret_cast<const uint4 *>(text + c);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (chunk + 16u * j >= end) return;
+      if (visit(chunk + 16u * j, v[j])) return;
+    }
+  }
+}
+
 // Start of the line containing `pos` when the previous '\n' lies in [tile_start, pos) (rank > 0).
 __device__ __forceinline__ uint64_t line_start_in_tile(const uint8_t *text, uint64_t tile_start, uint64_t pos) {
-  uint64_t chunk = (pos - 1) & ~15ull;
-  for (;;) {
-    const uint4 v = *reinterpret_cast<const uint4 *>(text + chunk);
+  uint64_t s = tile_start;  // not reached for rank > 0
+  walk_back4(text, (pos - 1) & ~15ull, tile_start, [&](uint64_t chunk, const uint4 &v) {
     uint32_t m = eq_mask16(v, 0x0a0a0a0au);
     if (chunk + 16 > pos) m &= (1u << static_cast<uint32_t>(pos - chunk)) - 1u;  // only bytes before pos
-    if (m) return chunk + (31 - __clz(m)) + 1;
-    if (chunk <= tile_start) return tile_start;  // cannot happen for rank > 0
-    chunk -= 16;
+    if (!m) return false;
+    s = chunk + (31 - __clz(m)) + 1;
+    return true;
+  });
+  return s;
+}
+
+// End of the bytes hs_scan sees when they run on from `from` (no NUL in [a, from)): the first NUL, or just past the first '\n',
+// else `limit`.
+__device__ __forceinline__ uint64_t scanned_end(const uint8_t *text, uint64_t from, uint64_t limit) {
+  uint64_t z = limit;
+  walk_fwd4(text, from & ~15ull, limit, [&](uint64_t chunk, const uint4 &v) {
+    const uint32_t lo = chunk < from ? static_cast<uint32_t>(from - chunk) : 0u;
+    const uint32_t hi = limit - chunk < 16 ? static_cast<uint32_t>(limit - chunk) : 16u;
+    const uint32_t range = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+    const uint32_t nl = eq_mask16(v, 0x0a0a0a0au) & range, nul = eq_mask16(v, 0u) & range;
+    if (!(nl | nul)) return false;
+    const uint32_t e = __ffs(nl | nul) - 1;
+    z = chunk + (((nl >> e) & 1u) ? e + 1 : e);
+    return true;
+  });
+  return z;
+}
+
+// What the confirm routines need to know about the line up to `upto` (a byte of a verified literal occurrence, so no
+// newline lies in [occurrence start, upto)): ONE backward walk finds the line start (rank > 0: the previous newline lies
+// in the tile) and applies the NUL rules of the reference (hyperscanner.c:207-217: leading NULs are skipped, the first
+// later NUL ends the scanned bytes) to [line start, upto).
+struct LineHead {
+  uint64_t s;    // line start
+  uint64_t a;    // first scanned byte when the piece starts at s: the lowest non-NUL byte of [s, upto), else upto
+  bool blocked;  // a NUL lies between a and upto: the scanned bytes end before upto
+};
+__device__ __forceinline__ LineHead line_head(const uint8_t *text, uint64_t tile_start, uint64_t carry_start, uint32_t rank, uint64_t upto) {
+  const uint64_t floor = rank == 0 ? carry_start : tile_start;
+  LineHead h{floor, upto, false};
+  bool nul_above = false;
+  if (upto > floor) {
+    walk_back4(text, (upto - 1) & ~15ull, floor & ~15ull, [&](uint64_t chunk, const uint4 &v) {
+      const uint32_t hi = upto - chunk < 16 ? static_cast<uint32_t>(upto - chunk) : 16u;
+      uint32_t range = (1u << hi) - 1u;
+      if (chunk < floor) range &= ~((1u << static_cast<uint32_t>(floor - chunk)) - 1u);
+      bool stop = false;
+      if (rank > 0) {
+        const uint32_t nl = eq_mask16(v, 0x0a0a0a0au) & range;
+        if (nl) {
+          const uint32_t q = 31 - __clz(nl);
+          h.s = chunk + q + 1;
+          range &= ~((2u << q) - 1u);
+          stop = true;
+        }
+      }
+      const uint32_t zero = eq_mask16(v, 0u);
+      const uint32_t nul = zero & range, data = ~zero & range;
+      if (data) {
+        if (nul_above || (nul && (data & ((1u << (31 - __clz(nul))) - 1u)))) h.blocked = true;
+        h.a = chunk + (__ffs(data) - 1);
+      }
+      if (nul) nul_above = true;
+      return stop || h.blocked;
+    });
   }
+  return h;
+}
+
+// Piece geometry shared by the confirm routines.  Returns false when nothing of the line can be scanned at `upto`.
+struct PieceView {
+  uint64_t line_no, a, limit;
+  bool whole;  // a came from the line head (the piece starts at the line start); else: a later piece of an over-long line
+};
+__device__ __forceinline__ bool piece_view(const uint8_t *text, uint64_t nbytes, const HgTileSum *sums, const HgTileBase *bases, uint64_t bs1, uint64_t pos,
+                                           uint32_t rank, uint64_t upto, PieceView *out) {
+  const uint64_t t = pos >> HG_TILE_SHIFT, tile_start = t << HG_TILE_SHIFT;
+  const HgTileBase tb = bases[t];
+  const LineHead h = line_head(text, tile_start, tb.cs, rank, upto);
+  const uint64_t k = (pos - h.s) / bs1;
+  const uint64_t ps = h.s + k * bs1;
+  out->limit = ps + bs1 < nbytes ? ps + bs1 : nbytes;
+  out->line_no = hg_line_index(text, sums[t], tb, tile_start, rank, h.s, bs1, bs1 < HG_TILE_BYTES) + k;
+  out->whole = k == 0;
+  if (k == 0) {
+    if (h.blocked) return false;
+    out->a = h.a;
+    return true;
+  }
+  // a later piece of a line longer than the scan buffer (rare): leading NULs of [ps, ...) are skipped byte by byte
+  uint64_t a = ps;
+  while (a < out->limit && text[a] == 0) a++;
+  out->a = a;
+  return a < out->limit;
 }
 
 // Literal-only SINGLEMATCH expression whose literal was verified at [fs, fs + len): the match is that occurrence if it
@@ -49,55 +173,19 @@ __device__ __forceinline__ uint64_t line_start_in_tile(const uint8_t *text, uint
 template <typename Emit>
 __device__ __forceinline__ void confirm_literal(const uint8_t *text, uint64_t nbytes, const HgTileSum *sums, const HgTileBase *bases, uint64_t bs1,
                                                 uint64_t pos, uint32_t rank, uint64_t fs, uint32_t len, Emit &&emit) {
-  const uint64_t t = pos >> HG_TILE_SHIFT, tile_start = t << HG_TILE_SHIFT;
-  const uint64_t s = rank == 0 ? bases[t].cs : line_start_in_tile(text, tile_start, pos);
-  const uint64_t k = (pos - s) / bs1;
-  const uint64_t ps = s + k * bs1;
-  const uint64_t limit = ps + bs1 < nbytes ? ps + bs1 : nbytes;
-  if (fs < ps || fs + len > limit) return;  // the occurrence straddles a forced break: no piece contains it
-  const uint64_t line_no = hg_line_index(text, sums[t], bases[t], tile_start, rank, s, bs1, bs1 < HG_TILE_BYTES) + k;
-  // [ps, fs): leading NULs are skipped, any later NUL ends the scanned bytes before the occurrence
-  uint64_t a = ps;
-  bool seen_data = false, blocked = false;
-  for (uint64_t chunk = ps & ~15ull; chunk < fs && !blocked; chunk += 16) {
-    const uint4 v = *reinterpret_cast<const uint4 *>(text + chunk);
-    const uint32_t lo = chunk < ps ? static_cast<uint32_t>(ps - chunk) : 0u;
-    const uint32_t hi = fs - chunk < 16 ? static_cast<uint32_t>(fs - chunk) : 16u;
-    const uint32_t range = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-    const uint32_t nul = eq_mask16(v, 0u) & range, data = ~eq_mask16(v, 0u) & range;
-    if (!seen_data) {
-      if (data) {
-        const uint32_t first = __ffs(data) - 1;
-        a = chunk + first;
-        seen_data = true;
-        if (nul >> first) blocked = true;  // a NUL after the first data byte
-      }
-    } else if (nul) {
-      blocked = true;
-    }
-  }
-  if (blocked) return;
-  if (!seen_data) a = fs;  // only NULs (or nothing) before the occurrence
-  // end of the scanned bytes: first NUL, or just past the first '\n', at or after the occurrence's end
-  uint64_t z = limit;
+  const uint32_t last_byte = text[fs + len - 1];  // independent of the walk: issued with its first loads
+  PieceView pv;
+  if (!piece_view(text, nbytes, sums, bases, bs1, pos, rank, fs, &pv)) return;
   const uint64_t from = fs + len;
-  if (from > fs && text[from - 1] == '\n') {
-    z = from;  // the literal ends with the line's newline
-  } else {
-    for (uint64_t chunk = from & ~15ull; chunk < limit; chunk += 16) {
-      const uint4 v = *reinterpret_cast<const uint4 *>(text + chunk);
-      const uint32_t lo = chunk < from ? static_cast<uint32_t>(from - chunk) : 0u;
-      const uint32_t hi = limit - chunk < 16 ? static_cast<uint32_t>(limit - chunk) : 16u;
-      const uint32_t range = ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-      const uint32_t nl = eq_mask16(v, 0x0a0a0a0au) & range, nul = eq_mask16(v, 0u) & range;
-      if (nl | nul) {
-        const uint32_t e = __ffs(nl | nul) - 1;
-        z = chunk + (((nl >> e) & 1u) ? e + 1 : e);
-        break;
-      }
-    }
+  if (from > pv.limit) return;  // the occurrence straddles a forced break: no piece contains it
+  uint64_t a = pv.a;
+  if (!pv.whole) {
+    if (a > fs) return;  // the piece starts (after its leading NULs) inside or after the occurrence
+    for (uint64_t i = a; i < fs; i++)
+      if (text[i] == 0) return;  // a NUL between the first scanned byte and the occurrence
   }
-  emit(line_no, static_cast<uint32_t>(fs + len - a), a, static_cast<uint32_t>(z - a));
+  const uint64_t z = last_byte == '\n' ? from : scanned_end(text, from, pv.limit);
+  emit(pv.line_no, static_cast<uint32_t>(from - a), a, static_cast<uint32_t>(z - a));
 }
 
 // Confirm one (candidate, pattern) for a "simple" SINGLEMATCH pattern.  follow_lds: this lane's private LDS slot
