@@ -60,7 +60,13 @@ __device__ __forceinline__ uint32_t not_newline_bits(uint32_t w) {
 // LDS is addressed through explicit address-space-3 pointers so that the out-of-line drain routine also gets ds_* instructions.
 using lds_u32 = __attribute__((address_space(3))) uint32_t;
 
-constexpr uint32_t QUEUE_CAP = 128;  // entries (8 B) per wave: drained as soon as it holds a full batch of 64, so it never exceeds 63 + 64
+// entries per wave: an iteration adds at most 64, and the queue is drained as soon as it holds a full batch of 64
+constexpr uint32_t queue_cap(int) { return 128u; }
+// dwords per entry: {chunk | rank << 10, tile} and, while LDS has room (filters up to 16 KiB, three workgroups per CU), also
+// {left, right, the chunk's four dwords} so that the drain does not read the text again (measured: re-reading costs ~15 % extra
+// HBM fetches on the round-1 workload, the streamed tiles have left the L2 by then)
+constexpr bool queue_stash(int log2) { return log2 <= 12; }
+constexpr uint32_t queue_entry_dw(int log2) { return queue_stash(log2) ? 8u : 2u; }
 
 template <int LOG2, bool WIDE>
 struct Probe {
@@ -102,7 +108,8 @@ struct StreamCtx {
   uint64_t nbytes;
   const lds_u32 *filter;
   const HgFilterExt *ext;      // the slots' neighbour conditions (HBM, L2-resident)
-  lds_u32 *queue;              // this wave's queue: {chunk inside the tile | newlines of the tile before it << 10, tile} per 16-byte chunk whose first level matched
+  lds_u32 *queue;              // this wave's queue, one entry per 16-byte chunk whose first level matched: {chunk inside the tile | newlines of the
+                               // tile before it << 10, tile, dword left of the chunk, dword right of it, the chunk} — the drain never re-reads the text
   lds_u32 *cand_count;         // the workgroup's candidate counter
   HgCand *seg;                 // the workgroup's private candidate segment
   uint32_t seg_cap, fold, wa, wb;
@@ -142,26 +149,37 @@ __device__ __noinline__ void drain_batch(const StreamCtx cx, uint32_t first, uin
   uint64_t g = 0;
   uint4 cur = make_uint4(0, 0, 0, 0);
   if (active) {
-    const uint32_t e_lo = cx.queue[2 * (first + lane)], e_hi = cx.queue[2 * (first + lane) + 1];
+    const lds_u32 *e = cx.queue + (first + lane) * queue_entry_dw(LOG2);
+    const uint32_t e_lo = e[0], e_hi = e[1];
     g = static_cast<uint64_t>(e_hi) * (HG_TILE_BYTES / 16) + (e_lo & 1023u);
     rank = e_lo >> 10;
-    cur = load_chunk_checked(cx.text16, cx.nbytes, g);
+    uint32_t left = 0, right = 0;
+    bool have_left = (e_lo & 63u) != 0, have_right = (e_lo & 63u) != 63u;  // stashed neighbours come from the adjacent lanes of the 1 KiB row
+    if (queue_stash(LOG2)) {
+      left = e[2];
+      right = e[3];
+      cur = make_uint4(e[4], e[5], e[6], e[7]);
+    } else {
+      cur = load_chunk_checked(cx.text16, cx.nbytes, g);
+      if (!WIDE) {  // the real neighbours (zero outside the text: a literal cannot extend past either end)
+        const uint32_t *text32 = reinterpret_cast<const uint32_t *>(cx.text16);
+        left = g ? text32[g * 4 - 1] : 0u;
+        if (((g + 1) << 4) < cx.nbytes) {
+          right = text32[g * 4 + 4];
+          const uint64_t rest = cx.nbytes - ((g + 1) << 4);
+          if (rest < 4) right &= (1u << (rest * 8)) - 1u;
+        }
+        have_left = have_right = true;
+      }
+    }
     const uint32_t l1 = Probe<LOG2, WIDE>::template probe4<false>(cx.filter, cx.fold, cx.wa, cx.wb, cur);
     if (WIDE) {
       hits = l1;
     } else if (l1) {
-      // the real neighbours (zero outside the text: a literal cannot extend past either end)
-      const uint32_t *text32 = reinterpret_cast<const uint32_t *>(cx.text16);
-      const uint32_t left = g ? text32[g * 4 - 1] : 0u;
-      uint32_t right = 0;
-      if (((g + 1) << 4) < cx.nbytes) {
-        right = text32[g * 4 + 4];
-        const uint64_t rest = cx.nbytes - ((g + 1) << 4);
-        if (rest < 4) right &= (1u << (rest * 8)) - 1u;
-      }
+      // a missing neighbour (first / last lane of the row) skips the condition on that side
       constexpr uint32_t BYTE_MASK = ((1u << LOG2) - 1u) << 2;
       // one window per lane and trip (a chunk rarely has two first-level matches): the lanes' matches sit at different k,
-      // and a loop over k would pay one HBM round trip for the conditions per k
+      // and a loop over k would pay one round trip for the conditions per k
       for (uint32_t todo = (l1 | (l1 >> 4)) & 15u; todo; todo &= todo - 1) {
         const uint32_t k = __ffs(todo) - 1;
         const uint32_t wk = k == 0 ? cur.x : (k == 1 ? cur.y : (k == 2 ? cur.z : cur.w));
@@ -171,7 +189,12 @@ __device__ __noinline__ void drain_batch(const StreamCtx cx, uint32_t first, uin
         const uint32_t f = wk | cx.fold;
         const uint32_t sa = (hg_dot4(f, cx.wa) & BYTE_MASK) >> 2, sb = (hg_dot4(f, cx.wb) & BYTE_MASK) >> 2;
         // read from HBM / L2: rare, and keeping the table out of LDS leaves room for more resident waves
-        const HgFilterExt ea = cx.ext[sa], eb = cx.ext[sb];
+        HgFilterExt ea = cx.ext[sa], eb = cx.ext[sb];
+        if (k == 0 && !have_left) ea.pm = eb.pm = 0;
+        if (k == 3 && !have_right) {
+          ea.nm &= HG_WINDOW_BYTES == 4 ? 0u : 0xFFu;
+          eb.nm &= HG_WINDOW_BYTES == 4 ? 0u : 0xFFu;
+        }
         const uint32_t prev = wp | cx.fold;
         const uint32_t next = (HG_WINDOW_BYTES == 4 ? wn : ((wk >> 24) | (wn << 8))) | cx.fold;
         const bool oka = ha && hg_ext_pass(ea, prev, next), okb = hb && hg_ext_pass(eb, prev, next);
@@ -261,15 +284,28 @@ __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, 
     }
     const uint64_t am = __builtin_amdgcn_ballot_w64(any);
     if (am) {  // remember the chunks; their windows are examined in batches of 64 (drain_batch)
+      // the dwords next to the chunk, from the adjacent lanes (DPP wave shifts; the row's edge lanes get 0 and skip that condition)
+      const uint32_t left = __builtin_amdgcn_update_dpp(0u, cur.w, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+      const uint32_t right = __builtin_amdgcn_update_dpp(0u, cur.x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
       if (any) {
         const uint32_t idx = qn + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(am >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(am), 0u));
-        cx.queue[2 * idx] = (static_cast<uint32_t>(it) * 64u + lane) | (before << 10);
-        cx.queue[2 * idx + 1] = static_cast<uint32_t>(tile);
+        lds_u32 *e = cx.queue + idx * queue_entry_dw(LOG2);
+        e[0] = (static_cast<uint32_t>(it) * 64u + lane) | (before << 10);
+        e[1] = static_cast<uint32_t>(tile);
+        if (queue_stash(LOG2)) {
+          e[2] = left;
+          e[3] = right;
+          e[4] = cur.x;
+          e[5] = cur.y;
+          e[6] = cur.z;
+          e[7] = cur.w;
+        }
       }
       qn += __popcll(am);
-      if (qn >= 64u) {
-        qn -= 64u;
-        drain_batch<LOG2, WIDE>(cx, qn, 64u, lane);
+      if (qn >= queue_cap(LOG2) - 64u) {
+        const uint32_t n = qn < 64u ? qn : 64u;
+        qn -= n;
+        drain_batch<LOG2, WIDE>(cx, qn, n, lane);
       }
     }
     seen += total;
@@ -332,7 +368,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_S
                                                                   uint32_t *__restrict__ seg_count, uint32_t *__restrict__ counters, uint32_t span) {
   // LDS, one block so that the filter starts at offset 0 (its byte offsets then fold into the ds_read instructions):
   //   window hash slots (4 B each) | per-wave chunk queues | candidate counter
-  constexpr uint32_t FILTER_U4 = (4u << LOG2) / 16, QUEUE_U4 = WG_WAVES * QUEUE_CAP * 8 / 16;
+  constexpr uint32_t FILTER_U4 = (4u << LOG2) / 16, QUEUE_U4 = WG_WAVES * queue_cap(LOG2) * queue_entry_dw(LOG2) * 4 / 16;
   __shared__ uint4 s_mem[FILTER_U4 + QUEUE_U4 + 1];
   {
     for (uint32_t i = threadIdx.x; i < FILTER_U4; i += WG_THREADS) s_mem[i] = filter16[i];
@@ -345,7 +381,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_S
   cx.text16 = text16;
   cx.nbytes = nbytes;
   cx.filter = (const lds_u32 *)(&s_mem[0]);
-  cx.queue = (lds_u32 *)(&s_mem[FILTER_U4]) + wave * QUEUE_CAP * 2;
+  cx.queue = (lds_u32 *)(&s_mem[FILTER_U4]) + wave * queue_cap(LOG2) * queue_entry_dw(LOG2);
   cx.cand_count = (lds_u32 *)(&s_mem[FILTER_U4 + QUEUE_U4]);
   cx.ext = reinterpret_cast<const HgFilterExt *>(ext16);
   cx.seg = cands + static_cast<uint64_t>(blockIdx.x) * seg_cap;  // this workgroup's private output segment
