@@ -1,8 +1,7 @@
-// Device-only fast paths of the confirm stage (hg_confirm_kernel).  Semantics are exactly those of the scalar
-// reference routines in hg_core.h (hg_verify_window, hg_confirm), which stay in use for multi-word / assertion
-// patterns and are what the host tests replay; here the same work is arranged for memory latency:
-//   * the literal verify compares 4 bytes at a time from aligned dword loads,
-//   * the line is located and scanned in aligned 16-byte chunks (SWAR newline / NUL detection),
+// Device-only fast paths of the confirm stage (hg_confirm_fast_kernel).  Semantics are exactly those of the scalar
+// reference routine in hg_core.h (hg_confirm), which stays in use for multi-word / all-matches patterns and is what the
+// host tests replay; here the same work is arranged for memory latency:
+//   * the line is located and scanned in aligned 16-byte chunks (SWAR newline / NUL detection), four loads in flight,
 //   * for "simple" patterns (one state word, no boundary conditions) the automaton step needs only reach[c],
 //     whose 16 loads per chunk are independent, and the follow table, which is staged in LDS per lane.
 #pragma once

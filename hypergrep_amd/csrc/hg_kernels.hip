@@ -3,12 +3,13 @@
 //
 //   hg_stream_kernel      one pass over the text in HBM: 16 B per lane coalesced loads, per-dword window
 //                         fingerprint (v_dot4_u32_u8) probed in an LDS cuckoo filter, exact newline counts
-//                         per 16 KiB wave tile, window hits ranked (wave prefix sums) and appended to HBM
-//                         with one atomic per wave
+//                         per 16 KiB wave tile; chunks with a fingerprint match are queued in LDS and examined
+//                         64 at a time (neighbour conditions), survivors go to the workgroup's candidate segment
 //   hg_tile_*             3-launch scan of the tile newline summaries -> global piece numbers
-//   hg_confirm_kernel     one lane per window hit: literal verify, locate the line piece, run the pattern automaton
+//   hg_verify_kernel      (candidate, literal) pairs flattened over the wave: one straight-line literal compare per lane
+//   hg_confirm_*          verified occurrences by automaton shape: locate the line piece, run the automaton, emit hits
 //   hg_always_on_kernel   patterns without a long enough required literal: every line, one wave per tile
-//   hg_key/gather/keep    ordering + SINGLEMATCH / duplicate rules (sort itself: rocPRIM radix sort)
+//   hg_key/keep/scatter   ordering + SINGLEMATCH / duplicate rules (sort itself: rocPRIM radix sort)
 //
 // Byte/integer work, HBM-bound: no MFMA anywhere.  Wave64 only.
 #include <hip/hip_runtime.h>
