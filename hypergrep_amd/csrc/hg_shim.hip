@@ -4,6 +4,11 @@
 // chunk is scanned by the device pipeline (HgScanner), and hit records come back to fill the same
 // batched result ring the reference fills in hs_callback() (hyperscanner.c:83-102).
 //
+// Ingest is a three-stage pipeline: a reader thread fills pinned slots (plain files: several pread stripes in
+// parallel; gzip / zstd: the decoder) and cuts them at line-piece boundaries, the calling thread copies slot k+1 to
+// HBM on a copy stream while slot k is scanned, and delivers slot k's hits from the pinned bytes while the reader is
+// already filling the next slot.
+//
 // What stays on the host: file IO, gzip/zstd decoding (the reference does that on the CPU too, through
 // zlibWrapper), cutting chunks at line boundaries, copying matched line bytes into the result ring and
 // calling back.  No byte of the text is matched on the CPU.
@@ -17,6 +22,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -80,17 +87,25 @@ struct Ctx {
   HgScanner *sc = nullptr;
   int device = 0;
   hipStream_t stream = nullptr;
-  uint8_t *h_buf = nullptr;  // pinned staging buffer
+  static constexpr int kSlots = 3, kDevBufs = 2;
+  uint8_t *h_slot[kSlots] = {nullptr, nullptr, nullptr};  // pinned staging buffers
   size_t h_cap = 0;
-  uint8_t *d_text = nullptr;
+  uint8_t *d_text[kDevBufs] = {nullptr, nullptr};
   size_t d_cap = 0;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_h2d[kDevBufs] = {nullptr, nullptr};
   std::vector<HgHit> hits;
   std::vector<HgHitAux> aux;
   ~Ctx() {
     if (sc) (void)hipSetDevice(device);
     delete sc;
-    if (h_buf) (void)hipHostFree(h_buf);
-    if (d_text) (void)hipFree(d_text);
+    for (uint8_t *p : h_slot)
+      if (p) (void)hipHostFree(p);
+    for (uint8_t *p : d_text)
+      if (p) (void)hipFree(p);
+    for (hipEvent_t e : ev_h2d)
+      if (e) (void)hipEventDestroy(e);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -119,7 +134,10 @@ Ctx *checkout(const std::shared_ptr<HgDb> &db, std::string *err) {
   c->db = db;
   c->device = device;
   if (HgScanner::create(db.get(), device, &c->sc, err) != HG_OK) return nullptr;
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_h2d[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_h2d[1], hipEventDisableTiming) != hipSuccess) {
     *err = "hipStreamCreate failed";
     return nullptr;
   }
@@ -133,19 +151,26 @@ void checkin(Ctx *c) {
   }
   g_idle.push_back(c);
 }
-bool ensure_buffers(Ctx *c, size_t cap) {
+// slots: pinned buffers needed (1 for a file that fits one chunk, else all)
+bool ensure_buffers(Ctx *c, size_t cap, int slots) {
   if (c->h_cap < cap) {
-    if (c->h_buf) (void)hipHostFree(c->h_buf);
-    c->h_buf = nullptr;
-    if (hipHostMalloc(reinterpret_cast<void **>(&c->h_buf), cap) != hipSuccess) return false;
+    for (uint8_t *&p : c->h_slot) {
+      if (p) (void)hipHostFree(p);
+      p = nullptr;
+    }
     c->h_cap = cap;
   }
+  for (int i = 0; i < slots; i++)
+    if (!c->h_slot[i] && hipHostMalloc(reinterpret_cast<void **>(&c->h_slot[i]), c->h_cap) != hipSuccess) return false;
   if (c->d_cap < cap) {
-    if (c->d_text) (void)hipFree(c->d_text);
-    c->d_text = nullptr;
-    if (hipMalloc(reinterpret_cast<void **>(&c->d_text), cap + 16) != hipSuccess) return false;
+    for (uint8_t *&p : c->d_text) {
+      if (p) (void)hipFree(p);
+      p = nullptr;
+    }
     c->d_cap = cap;
   }
+  for (int i = 0; i < (slots > 1 ? Ctx::kDevBufs : 1); i++)
+    if (!c->d_text[i] && hipMalloc(reinterpret_cast<void **>(&c->d_text[i]), c->d_cap + 16) != hipSuccess) return false;
   return true;
 }
 
@@ -208,6 +233,51 @@ class Reader {
   // Fill dst with up to n bytes; returns bytes produced, 0 at EOF, -1 on error.
   long read(uint8_t *dst, size_t n) {
     if (kind_ == 0) {
+      // regular files: the request is cut into stripes read by parallel preads (one thread copies ~5 GB/s out of the page
+      // cache, the host link takes ten times that); pipes and the like: plain read()
+      auto pread_all = [this](uint8_t *p, size_t len, off_t at) -> long {
+        size_t total = 0;
+        while (total < len) {
+          ssize_t r = ::pread(fd_, p + total, len - total, at + static_cast<off_t>(total));
+          if (r < 0) return -1;
+          if (r == 0) break;
+          total += static_cast<size_t>(r);
+        }
+        return static_cast<long>(total);
+      };
+      if (size_hint_) {
+        const size_t left = static_cast<size_t>(off_) < size_hint_ ? size_hint_ - static_cast<size_t>(off_) : 0;
+        const size_t want = std::min(n, left);
+        if (want == 0) {  // at the size seen at open: the file may have grown meanwhile
+          const long g = pread_all(dst, n, off_);
+          if (g > 0) off_ += g;
+          return g;
+        }
+        const size_t kStripe = static_cast<size_t>(8) << 20;
+        const unsigned workers = static_cast<unsigned>(std::min<size_t>(read_threads(), want / kStripe));
+        long got;
+        if (workers <= 1) {
+          got = pread_all(dst, want, off_);
+        } else {
+          std::vector<long> part(workers, 0);
+          std::vector<std::thread> pool;
+          const size_t per = (want / workers + 4095) & ~static_cast<size_t>(4095);
+          for (unsigned w = 0; w < workers; w++) {
+            const size_t b = std::min(want, per * w), e = w + 1 == workers ? want : std::min(want, per * (w + 1));
+            pool.emplace_back([&, w, b, e] { part[w] = pread_all(dst + b, e - b, off_ + static_cast<off_t>(b)); });
+          }
+          for (auto &t : pool) t.join();
+          got = 0;
+          for (unsigned w = 0; w < workers; w++) {
+            const size_t b = std::min(want, per * w), e = w + 1 == workers ? want : std::min(want, per * (w + 1));
+            if (part[w] < 0) return -1;
+            got += part[w];
+            if (static_cast<size_t>(part[w]) < e - b) break;  // the file shrank: stop at the first short stripe
+          }
+        }
+        if (got > 0) off_ += got;
+        return got;
+      }
       size_t total = 0;
       while (total < n) {
         ssize_t r = ::read(fd_, dst + total, n - total);
@@ -257,7 +327,16 @@ class Reader {
   }
 
  private:
+  static unsigned read_threads() {
+    if (const char *env = std::getenv("HYPERGREP_READ_THREADS")) {
+      long v = std::atol(env);
+      if (v >= 1 && v <= 64) return static_cast<unsigned>(v);
+    }
+    const unsigned hw = std::thread::hardware_concurrency();
+    return hw >= 16 ? 8u : (hw >= 4 ? hw / 2 : 1u);
+  }
   int fd_ = -1, kind_ = 0;
+  off_t off_ = 0;  // plain regular files are read with pread from here
   gzFile gz_ = nullptr;
   void *zds_ = nullptr;
   std::vector<uint8_t> zin_;
@@ -344,75 +423,155 @@ extern "C" int hyperscan(char *file_name, const char *const *patterns, const uns
 
   const uint64_t bs1 = static_cast<uint64_t>(buffer_size) - 1;
   size_t cap = chunk_bytes();
-  if (!in.compressed() && in.size_hint() && in.size_hint() < cap) cap = std::max<size_t>(in.size_hint() + 16, 1 << 16);
+  const bool one_chunk = !in.compressed() && in.size_hint() && in.size_hint() < cap;
+  if (one_chunk) cap = std::max<size_t>(in.size_hint() + 16, 1 << 16);
   cap = std::max<size_t>(cap, static_cast<size_t>(std::min<uint64_t>(2 * bs1 + 16, static_cast<uint64_t>(1) << 32)));
-  if (hipSetDevice(ctx->device) != hipSuccess || !ensure_buffers(ctx, cap)) {
+  const int nslots = one_chunk ? 1 : Ctx::kSlots;
+  if (hipSetDevice(ctx->device) != hipSuccess || !ensure_buffers(ctx, cap, nslots)) {
     std::fprintf(stderr, "ERROR: Unable to allocate scratch space. Exiting. (device buffers)\n");
     return HYPERSCANNER_SCRATCH;
   }
 
+  // ---- stage 1: the reader thread fills slots and cuts them at piece boundaries
+  struct Slot {
+    size_t cut = 0;     // bytes to scan (whole pieces)
+    bool last = false;  // nothing follows
+    int state = 0;      // 0 free (reader's), 1 ready (consumer's)
+  };
+  Slot slots[Ctx::kSlots];
+  std::mutex mu;
+  std::condition_variable cv;
+  bool abandon = false;  // the consumer stopped early (match limit, error)
+  std::thread reader([&] {
+    std::vector<uint8_t> carry;  // bytes after the cut, they open the next slot
+    bool eof = false;
+    for (unsigned k = 0;; k++) {
+      Slot &s = slots[k % nslots];
+      uint8_t *buf = ctx->h_slot[k % nslots];
+      {
+        std::unique_lock<std::mutex> lock(mu);
+        cv.wait(lock, [&] { return s.state == 0 || abandon; });
+        if (abandon) return;
+      }
+      size_t have = carry.size();
+      if (have) std::memcpy(buf, carry.data(), have);
+      carry.clear();
+      while (!eof && have < cap) {
+        const long got = in.read(buf + have, cap - have);
+        if (got <= 0) {  // end of the stream; a read error ends it like gzgets returning NULL
+          eof = true;
+          break;
+        }
+        have += static_cast<size_t>(got);
+      }
+      size_t cut = have;
+      if (!eof && have) {  // cut at a piece boundary so that every piece is scanned whole
+        const void *nl = memrchr(buf, '\n', have);
+        if (nl) cut = static_cast<size_t>(static_cast<const uint8_t *>(nl) - buf) + 1;
+        else cut = static_cast<size_t>((have / bs1) * bs1);  // one unterminated line: stop at a forced break
+        if (!cut) cut = have;
+        carry.assign(buf + cut, buf + have);
+      }
+      {
+        std::lock_guard<std::mutex> lock(mu);
+        s.cut = cut;
+        s.last = eof && carry.empty();
+        s.state = 1;
+      }
+      cv.notify_all();
+      if (eof && carry.empty()) return;
+    }
+  });
+  auto stop_reader = [&] {
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      abandon = true;
+    }
+    cv.notify_all();
+    reader.join();
+  };
+
+  // ---- stages 2 and 3: copy to HBM (one chunk ahead when the reader is), scan, deliver
   uint64_t line_base = 0;  // pieces delivered to the scanner so far == reference line_number of the chunk's first piece
-  size_t have = 0;         // bytes carried over from the previous chunk
-  bool eof = false, stop = false;
+  bool stop = false;
   int rc = 0;
-  while (!stop && (!eof || have)) {
-    while (!eof && have < cap) {
-      long got = in.read(ctx->h_buf + have, cap - have);
-      if (got < 0) { eof = true; break; }  // a read error ends the stream like gzgets returning NULL
-      if (got == 0) { eof = true; break; }
-      have += static_cast<size_t>(got);
+  bool copied[Ctx::kSlots] = {false, false, false};
+  auto issue_copy = [&](unsigned k) -> bool {  // slot k -> device buffer k % 2, asynchronously
+    const int sl = static_cast<int>(k % nslots), db_i = static_cast<int>(k % Ctx::kDevBufs);
+    if (copied[sl]) return true;
+    copied[sl] = true;
+    if (!slots[sl].cut) return true;
+    return hipMemcpyAsync(ctx->d_text[nslots > 1 ? db_i : 0], ctx->h_slot[sl], slots[sl].cut, hipMemcpyHostToDevice, ctx->copy_stream) == hipSuccess &&
+           hipEventRecord(ctx->ev_h2d[db_i], ctx->copy_stream) == hipSuccess;
+  };
+  for (unsigned k = 0; !stop; k++) {
+    const int sl = static_cast<int>(k % nslots);
+    Slot &s = slots[sl];
+    bool next_ready = false;
+    {
+      std::unique_lock<std::mutex> lock(mu);
+      cv.wait(lock, [&] { return s.state == 1; });
+      next_ready = nslots > 1 && !s.last && slots[(k + 1) % nslots].state == 1;
     }
-    if (!have) break;
-    // cut the chunk at a piece boundary so that every piece is scanned whole
-    size_t cut = have;
-    if (!eof) {
-      const void *nl = memrchr(ctx->h_buf, '\n', have);
-      if (nl) cut = static_cast<size_t>(static_cast<const uint8_t *>(nl) - ctx->h_buf) + 1;
-      else cut = static_cast<size_t>((have / bs1) * bs1);  // one unterminated line: stop at a forced break
-      if (!cut) cut = have;
-    }
-    if (hipMemcpyAsync(ctx->d_text, ctx->h_buf, cut, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { rc = HYPERSCANNER_SCAN; break; }
-    HgScanOutput out{};
-    int src = ctx->sc->scan(ctx->d_text, cut, buffer_size, line_base, ctx->stream, &out);
-    if (src != HG_OK) {
-      std::fprintf(stderr, "ERROR: Unable to scan buffer. Exiting. (%s)\n", ctx->sc->last_error().c_str());
-      rc = HYPERSCANNER_SCAN;
-      break;
-    }
-    ctx->hits.resize(out.n_hits);
-    ctx->aux.resize(out.n_hits);
-    if (out.n_hits) {
-      if (hipMemcpyAsync(ctx->hits.data(), out.d_hits, out.n_hits * sizeof(HgHit), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-          hipMemcpyAsync(ctx->aux.data(), out.d_aux, out.n_hits * sizeof(HgHitAux), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-          hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    const uint8_t *host = ctx->h_slot[sl];
+    const size_t cut = s.cut;
+    const bool last = s.last;
+    if (cut) {
+      uint8_t *d_text = ctx->d_text[nslots > 1 ? k % Ctx::kDevBufs : 0];
+      if (!issue_copy(k) || (next_ready && !issue_copy(k + 1)) ||  // the next chunk travels while this one is scanned
+          hipStreamWaitEvent(ctx->stream, ctx->ev_h2d[k % Ctx::kDevBufs], 0) != hipSuccess) {
         rc = HYPERSCANNER_SCAN;
         break;
       }
-    }
-    // deliver line by line; inside a line reports go out by ascending end offset, then id (hs_scan order)
-    size_t i = 0;
-    while (i < ctx->hits.size() && !stop) {
-      size_t j = i;
-      while (j < ctx->hits.size() && ctx->hits[j].line_no == ctx->hits[i].line_no) j++;
-      if (j - i > 1) {
-        std::vector<size_t> order(j - i);
-        for (size_t k = 0; k < order.size(); k++) order[k] = i + k;
-        std::sort(order.begin(), order.end(), [&](size_t x, size_t y) {
-          if (ctx->hits[x].to != ctx->hits[y].to) return ctx->hits[x].to < ctx->hits[y].to;
-          return ctx->hits[x].id < ctx->hits[y].id;
-        });
-        for (size_t k : order) ring.push(ctx->hits[k].id, ctx->hits[k].line_no, ctx->h_buf + ctx->aux[k].start, ctx->aux[k].len);
-      } else {
-        ring.push(ctx->hits[i].id, ctx->hits[i].line_no, ctx->h_buf + ctx->aux[i].start, ctx->aux[i].len);
+      HgScanOutput out{};
+      int src = ctx->sc->scan(d_text, cut, buffer_size, line_base, ctx->stream, &out);
+      if (src != HG_OK) {
+        std::fprintf(stderr, "ERROR: Unable to scan buffer. Exiting. (%s)\n", ctx->sc->last_error().c_str());
+        rc = HYPERSCANNER_SCAN;
+        break;
       }
-      // the reference checks the limit after each line's hs_scan returns (hyperscanner.c:222-224)
-      if (max_match_count > 0 && ring.delivered >= max_match_count) stop = true;
-      i = j;
+      ctx->hits.resize(out.n_hits);
+      ctx->aux.resize(out.n_hits);
+      if (out.n_hits) {
+        if (hipMemcpyAsync(ctx->hits.data(), out.d_hits, out.n_hits * sizeof(HgHit), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(ctx->aux.data(), out.d_aux, out.n_hits * sizeof(HgHitAux), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+          rc = HYPERSCANNER_SCAN;
+          break;
+        }
+      }
+      // deliver line by line; inside a line reports go out by ascending end offset, then id (hs_scan order)
+      size_t i = 0;
+      while (i < ctx->hits.size() && !stop) {
+        size_t j = i;
+        while (j < ctx->hits.size() && ctx->hits[j].line_no == ctx->hits[i].line_no) j++;
+        if (j - i > 1) {
+          std::vector<size_t> order(j - i);
+          for (size_t q = 0; q < order.size(); q++) order[q] = i + q;
+          std::sort(order.begin(), order.end(), [&](size_t x, size_t y) {
+            if (ctx->hits[x].to != ctx->hits[y].to) return ctx->hits[x].to < ctx->hits[y].to;
+            return ctx->hits[x].id < ctx->hits[y].id;
+          });
+          for (size_t q : order) ring.push(ctx->hits[q].id, ctx->hits[q].line_no, host + ctx->aux[q].start, ctx->aux[q].len);
+        } else {
+          ring.push(ctx->hits[i].id, ctx->hits[i].line_no, host + ctx->aux[i].start, ctx->aux[i].len);
+        }
+        // the reference checks the limit after each line's hs_scan returns (hyperscanner.c:222-224)
+        if (max_match_count > 0 && ring.delivered >= max_match_count) stop = true;
+        i = j;
+      }
+      line_base += out.n_pieces;
     }
-    line_base += out.n_pieces;
-    std::memmove(ctx->h_buf, ctx->h_buf + cut, have - cut);
-    have -= cut;
+    copied[sl] = false;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      s.state = 0;  // the slot goes back to the reader
+    }
+    cv.notify_all();
+    if (last) break;
   }
+  stop_reader();
+  (void)hipStreamSynchronize(ctx->copy_stream);  // a copy issued ahead may still be in flight
   ring.flush();
   return rc;
 }
