@@ -424,3 +424,56 @@ def test_chunked_pipeline_matches_oracle(torch_cuda, monkeypatch):
     sc2 = device.Scanner(device.Database(pats2, ids=ids + [999]), 0)
     sc2.scan(text.data_ptr(), 20 << 20)
     assert sorted(sc2.hits()) == want2
+
+
+def test_full_size_properties_32gib(torch_cuda, monkeypatch):
+    """BASELINE config 3 at its full size (256 patterns, 32 GiB in HBM): size-independent properties instead of an oracle
+    run — exact line count, strict (line, id, to) order, idempotence, the chunked pipeline and the single-pass path agree
+    record for record, and the hits of the first 2 MiB equal the oracle's."""
+    from hypergrep_amd import benchspec, device
+
+    torch = torch_cuda
+    free, _ = torch.cuda.mem_get_info()
+    if free < 80 << 30:
+        pytest.skip("needs 80 GiB of free HBM")
+    patterns, needles, hpm = benchspec.c3_spec()
+    ids = list(range(len(patterns)))
+    nbytes = 32 << 30
+    text = torch.empty(nbytes + 64, dtype=torch.uint8, device="cuda:0")
+    device.synth_device(text.data_ptr(), nbytes, benchspec.SEED_BASE + 3, needles, hpm)
+    torch.cuda.synchronize()
+    newlines = sum(int((text[o:min(o + (4 << 30), nbytes)] == 10).sum()) for o in range(0, nbytes, 4 << 30))
+    db = device.Database(patterns, ids=ids)
+    db.tune(bytes(text[: 4 << 20].cpu().numpy()))
+    sc = device.Scanner(db, 0)
+
+    def run():
+        st = sc.scan(text.data_ptr(), nbytes)
+        buf = torch.empty((st.n_hits, 2), dtype=torch.int64, device="cuda:0")
+        assert sc.copy_hits_to(buf.data_ptr(), st.n_hits) == st.n_hits
+        torch.cuda.synchronize()
+        return st, buf
+
+    st, a = run()
+    assert st.n_lines == newlines + (0 if int(text[nbytes - 1]) == 10 else 1)  # every line is one piece; the last one may be cut short
+    assert st.stream_launches == 4  # the chunked pipeline
+    # record = (u64 line, u32 id, u32 to): strictly increasing in (line, id, to)
+    line, rest = a[:, 0], a[:, 1]
+    ident, to = rest & 0xFFFFFFFF, (rest >> 32) & 0xFFFFFFFF
+    key = (ident << 32) | to
+    same_line = line[1:] == line[:-1]
+    assert bool(((line[1:] > line[:-1]) | (same_line & (key[1:] > key[:-1]))).all())
+    assert 0.009 < st.n_hits / st.n_lines < 0.012  # 1.05 % of lines carry a matching needle
+    st2, b = run()
+    assert st2.n_hits == st.n_hits and bool((a == b).all())  # idempotent
+    monkeypatch.setenv("HG_CHUNK_TILES", str(1 << 30))  # one pass, no side stream
+    st3, c = run()
+    assert st3.stream_launches == 1 and st3.n_hits == st.n_hits and st3.n_lines == st.n_lines and bool((a == c).all())
+    monkeypatch.delenv("HG_CHUNK_TILES")
+    # the head of the text against the oracle
+    head_n = 2 << 20
+    host = bytes(text[:head_n].cpu().numpy())
+    head_n = host.rfind(b"\n") + 1
+    want, nl = oracle_hits(host[:head_n], patterns, ids=ids)
+    got = [h[:3] for h in sc.hits(limit=len(want) + 16) if h[0] < nl]
+    assert sorted(got) == [w[:3] for w in want]
