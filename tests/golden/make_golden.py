@@ -115,6 +115,41 @@ def main() -> None:
 
     with open(os.path.join(HERE, "reference_tables.json"), "w", encoding="utf-8") as out:
         json.dump(table_out, out, indent=1, sort_keys=True)
+
+    # ---- the CLI layer (multiscanner.py): argument handling and pattern conversions, as input -> output vectors ----
+    import shlex
+
+    cli = {"argv": [], "to_basic_regular_expressions": [], "to_gnu_regular_expressions": []}
+    argvs = ["pattern1 file1 file2 file3", "pattern1 -e pattern2 file1", "pattern1 -f regex.txt file1", "pattern1 -e pattern2 -f regex.txt file1",
+             "-e pattern2 pattern1 -e pattern3 file1 file2", "pattern1 file1 -e pattern2 file2 -e pattern3 file3 f4", "p1 f1 f2 f3", "-e p2 p1 -e p3 f1 f2",
+             "p1 f1 -e p2 f2 -e p3 f3 f4", "-i -n -H foo a b", "-c -h foo a", "-E -o 'a|b' x", "-P -q foo x y", "-l -s -m 3 foo x", "-L foo x", "-t --no-order --no-sort --mp foo b a",
+             "--no-gnu -G foo x", "-a foo x", "foo"]
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            with open("regex.txt", "wt", encoding="utf-8") as f:
+                f.write("filepattern1\nfilepattern2")
+            for argv in argvs:
+                ns = multiscanner.parse_args(shlex.split(argv))
+                attrs = {k: v for k, v in vars(ns).items() if k != "parser"}
+                cli["argv"].append({"argv": argv, "attributes": attrs, "files": multiscanner.get_argparse_files(ns),
+                                    "patterns": multiscanner.get_argparse_patterns(ns)})
+        finally:
+            os.chdir(cwd)
+    bre_inputs = [["test"], ["^test.*[test]$"], ["^test.*[test]+?(){}|$"], [r"^test.*[test]+?(){}|\^\$\*\.\[\]\+\?\(\)\{\}\|$"],
+                  [r"data \((?P<v0>.*?) (?P<v1>.*?)"], [r"a\|b", r"x\{2\}", "a{2}"], [r"foo\(bar\)\+", "(x)"], [r"tab\tq+", r"\w\+"], ["", "|"]]
+    for inp in bre_inputs:
+        try:
+            cli["to_basic_regular_expressions"].append({"args": inp, "returns": multiscanner.to_basic_regular_expressions(inp)})
+        except ValueError:
+            cli["to_basic_regular_expressions"].append({"args": inp, "raises": "ValueError"})
+    gnu_inputs = [["<foo>"], [r"<foo>\<foo\>"], [r"<foo>\<foo\>\\<foo\\>"], [r"\<a\>|\<b\>", "x"], [r"a\b\<"]]
+    for inp in gnu_inputs:
+        cli["to_gnu_regular_expressions"].append({"args": inp, "returns": multiscanner.to_gnu_regular_expressions(inp)})
+    with open(os.path.join(HERE, "cli_tables.json"), "w", encoding="utf-8") as out:
+        json.dump(cli, out, indent=1, sort_keys=True)
+    print(f"cli tables: {len(cli['argv'])} argv cases, {len(bre_inputs)} BRE and {len(gnu_inputs)} GNU conversion cases from the reference's functions")
     n_cases = sum(len(v) for v in table_out.values())
     print(f"reference tables: {n_cases} engine-touching cases reproduced through the reference shim + oracle libhs")
 
