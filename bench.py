@@ -8,7 +8,8 @@
 
 One "step" = one pass of the whole scan pipeline (stream kernel, tile scan, confirm, order + de-duplicate) over this
 rank's 32 GiB shard; for N > 1 each rank scans its own shard (weak scaling: files / chunks shard with no data-path
-exchange), then the ranks all-gather their (lines, hits) counts over RCCL and send their hit records to rank 0.
+exchange), then the ranks all-gather their (lines, hits) counts over RCCL and send their hit records to rank 0; that gather
+runs on its own stream and overlaps the next step's scan (every gather has finished when the timed region ends).
 Rank 0 prints ONE JSON line.  `roofline` prices the streaming kernel against HBM; `cpu_baseline` times the oracle (a
 CPU port of the reference's per-line path) on a bounded sample of the same text on the GPU box's host cores.
 """
@@ -79,22 +80,38 @@ def main() -> None:
     sc = device.Scanner(db, local_rank)
     stream = torch.cuda.current_stream().cuda_stream
 
-    hit_buf = None
-    recv_bufs: list = []
+    # N > 1: the hit gather of step k runs on its own stream and overlaps the scan of step k + 1 (two buffer sets);
+    # the final synchronize of the timed region waits for every gather
+    comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
+    hit_bufs: list = [None, None]
+    recv_sets: list = [[], []]
+    slot_free: list = [None, None]  # event: the gather that last used the slot has finished
+    step_no = [0]
 
     def step():
         st = sc.scan(text.data_ptr(), nbytes, stream=stream)
         if world > 1:
-            nonlocal hit_buf, recv_bufs
+            slot = step_no[0] & 1
+            step_no[0] += 1
             totals = shard.exchange_counts(st.n_lines, st.n_hits, dev)
             # hit records (u64 line, u32 id, u32 to) -> a tensor, shard-local line numbers made global, sent to rank 0
             need = max(int(totals[:, 1].max()), 1)
-            if hit_buf is None or hit_buf.shape[0] < need:
-                hit_buf = torch.empty((need + need // 8, 2), dtype=torch.int64, device=dev)
-                recv_bufs = [torch.empty_like(hit_buf) for _ in range(world - 1)] if rank == 0 else []
+            if hit_bufs[slot] is None or hit_bufs[slot].shape[0] < need:
+                if slot_free[slot] is not None:
+                    slot_free[slot].synchronize()
+                hit_bufs[slot] = torch.empty((need + need // 8, 2), dtype=torch.int64, device=dev)
+                recv_sets[slot] = [torch.empty_like(hit_bufs[slot]) for _ in range(world - 1)] if rank == 0 else []
+            main = torch.cuda.current_stream()
+            if slot_free[slot] is not None:
+                main.wait_event(slot_free[slot])
+            hit_buf = hit_bufs[slot]
             n = sc.copy_hits_to(hit_buf.data_ptr(), st.n_hits, stream=stream)
             hit_buf[:n, 0] += shard.line_offset(totals, rank)
-            shard.gather_hits(hit_buf[:n], totals, recv_bufs)
+            ready = main.record_event()
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(ready)
+                shard.gather_hits(hit_buf[:n], totals, recv_sets[slot])
+                slot_free[slot] = comm_stream.record_event()
         return st
 
     for _ in range(args.warmup):
