@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <array>
 #include <bitset>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -991,99 +992,117 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
   for (auto &kw : keyed) values.push_back(kw.second.value);
   std::sort(values.begin(), values.end());
   values.erase(std::unique(values.begin(), values.end()), values.end());
+  // Single-probe slots.  Per table size and candidate weight vector the cost is the expected false-positive rate per
+  // text dword (slot shared by windows whose fingerprints agree on b bits admits 2^-b of all dwords); the smallest
+  // table that stays under the target wins: up to 16 KiB three stream workgroups fit on a CU, beyond that two or one.
   bool placed = false;
-  for (uint32_t attempt = 0; attempt < (HG_FILTER_MAX_LOG2 - HG_FILTER_MIN_LOG2 + 1) * HG_SLOT_WEIGHT_NCHOICES && !placed; attempt++) {
-    // smallest table first; for each size every weight pair
-    const uint32_t k = HG_FILTER_MIN_LOG2 + attempt / HG_SLOT_WEIGHT_NCHOICES;
-    const uint32_t wa = HG_SLOT_WEIGHT_CHOICES[attempt % HG_SLOT_WEIGHT_NCHOICES][0], wb = HG_SLOT_WEIGHT_CHOICES[attempt % HG_SLOT_WEIGHT_NCHOICES][1];
-    if (values.size() * 100 > (size_t(1) << k) * (k == HG_FILTER_MAX_LOG2 ? 49 : 45)) continue;  // keep the load under 45 %
-    const uint32_t byte_mask = ((1u << k) - 1u) << 2;
-    struct Entry { uint32_t sa, sb, fp; };
-    std::vector<Entry> entries;
-    {
-      std::vector<std::array<uint32_t, 3>> keys;  // values with the same slot pair and fingerprint are one entry
+  {
+    std::vector<uint32_t> cand_weights;
+    for (uint32_t i = 0; i < HG_SLOT_WEIGHT_NCHOICES; i++) {
+      cand_weights.push_back(HG_SLOT_WEIGHT_CHOICES[i][0]);
+      cand_weights.push_back(HG_SLOT_WEIGHT_CHOICES[i][1]);
+    }
+    auto slot_words = [&](uint32_t k, uint32_t weights, std::vector<uint32_t> &words) -> double {
+      const uint32_t byte_mask = ((1u << k) - 1u) << 2;
+      words.assign(size_t(1) << k, HG_FILTER_EMPTY);
+      std::vector<uint8_t> used(size_t(1) << k, 0);
       for (uint32_t v : values) {
-        uint32_t sa = hg_slot(v, wa, byte_mask) >> 2, sb = hg_slot(v, wb, byte_mask) >> 2;
-        keys.push_back({std::min(sa, sb), std::max(sa, sb), hg_hash_window(v)});
+        const uint32_t sl = hg_slot(v, weights, byte_mask) >> 2, fp = hg_hash_window(v) & 0xFFFFu;
+        uint32_t &w = words[sl];
+        if (!used[sl]) {
+          w = 0xFFFF0000u | fp;
+          used[sl] = 1;
+        } else {
+          const uint32_t care = (w >> 16) & ~((w ^ fp) & 0xFFFFu);  // keep the bits on which all fingerprints agree
+          w = (care << 16) | (w & care);
+        }
       }
-      std::sort(keys.begin(), keys.end());
-      keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
-      for (auto &key : keys) entries.push_back({key[0], key[1], key[2]});
-    }
-    std::vector<int32_t> owner(size_t(1) << k, -1);  // entry index owning the slot
-    uint64_t rng = 0x9E3779B97F4A7C15ull;
-    placed = true;
-    for (size_t e = 0; e < entries.size() && placed; e++) {
-      int32_t cur = static_cast<int32_t>(e);
-      bool ok = false;
-      for (int kick = 0; kick < 4000; kick++) {
-        uint32_t sa = entries[cur].sa, sb = entries[cur].sb;
-        if (owner[sa] < 0) { owner[sa] = cur; ok = true; break; }
-        if (owner[sb] < 0) { owner[sb] = cur; ok = true; break; }
-        rng = rng * 6364136223846793005ull + 1442695040888963407ull;
-        uint32_t slot = ((rng >> 33) & 1) ? sa : sb;
-        std::swap(cur, owner[slot]);
-      }
-      if (!ok) placed = false;
-    }
-    if (!placed) continue;
-    db.filter.assign(size_t(1) << k, HG_FILTER_EMPTY);
-    db.ext.assign(size_t(1) << k, HgFilterExt{0, 0, 0, 0});
-    std::vector<bool> seen(size_t(1) << k, false);
-    std::vector<uint32_t> slot_n16(size_t(1) << k, 0);
-    db.filter_log2 = k;
-    db.weights_a = wa;
-    db.weights_b = wb;
-    // per owning slot: next-two-bytes hash (kept only if all its windows agree) and the neighbour-dword conditions
-    // (byte-wise agreement of all its windows)
-    auto merge = [](uint32_t &val, uint32_t &mask, uint32_t v2, uint32_t m2) {
-      uint32_t keep = 0;
-      for (int b = 0; b < 4; b++) {
-        uint32_t bm = 0xFFu << (8 * b);
-        if ((mask & bm) && (m2 & bm) && ((val ^ v2) & bm) == 0) keep |= bm;
-      }
-      mask = keep;
-      val &= keep;
+      double fp_rate = 0;
+      for (size_t sl = 0; sl < words.size(); sl++)
+        if (used[sl]) fp_rate += std::ldexp(1.0, -static_cast<int>(__builtin_popcount(words[sl] >> 16)));
+      return fp_rate / static_cast<double>(words.size());
     };
-    for (size_t wi = 0; wi < keyed.size(); wi++) {
-      const HgWindow &w = keyed[wi].second;
-      const HgFactor &f = db.factors[w.factor_off >> 8];
-      const int o = static_cast<int>(w.factor_off & 0xff);
-      uint32_t pv = 0, pm = 0, nv = 0, nm = 0;
-      for (int b = 0; b < 4; b++) {
-        int jp = o - 4 + b, jn = o + static_cast<int>(HG_WINDOW_BYTES) + b;
-        if (jp >= 0) { pv |= static_cast<uint32_t>(f.lit[jp]) << (8 * b); pm |= 0xFFu << (8 * b); }
-        if (jn < static_cast<int>(f.len)) { nv |= static_cast<uint32_t>(f.lit[jn]) << (8 * b); nm |= 0xFFu << (8 * b); }
+    double best_rate = 1e9;
+    uint32_t best_k = 0, best_w = 0;
+    for (uint32_t k = HG_FILTER_MIN_LOG2; k <= HG_FILTER_MAX_LOG2 && !placed; k++) {
+      if (values.size() > (size_t(1) << k)) continue;  // hopeless: more windows than slots
+      double k_rate = 1e9;
+      uint32_t k_w = 0;
+      for (uint32_t weights : cand_weights) {
+        std::vector<uint32_t> words;
+        const double rate = slot_words(k, weights, words);
+        if (rate < k_rate) { k_rate = rate; k_w = weights; }
       }
-      pv = (pv | fold) & pm;
-      nv = (nv | fold) & nm;
-      if (!fold) {  // case-insensitive letters cannot be compared exactly without folding: drop them
+      if (k_rate < best_rate) { best_rate = k_rate; best_k = k; best_w = k_w; }
+      if (k_rate <= (k <= 12 ? 5e-4 : 3e-4)) {
+        best_rate = k_rate;
+        best_k = k;
+        best_w = k_w;
+        placed = true;
+      }
+    }
+    if (!placed && best_k && best_rate <= 2e-3 && values.size() * 100 <= (size_t(1) << HG_FILTER_MAX_LOG2) * 45) placed = true;  // dense, but still cheaper than wide mode
+    if (placed) {
+      const uint32_t k = best_k, wa = best_w;
+      const uint32_t byte_mask = ((1u << k) - 1u) << 2;
+      slot_words(k, wa, db.filter);
+      db.ext.assign(size_t(1) << k, HgSlotInfo{});
+      db.filter_log2 = k;
+      db.weights_a = wa;
+      db.weights_b = wa;  // unused outside wide mode
+      // per slot: the neighbour-dword conditions (byte-wise agreement of all its windows)
+      auto merge = [](uint32_t &val, uint32_t &mask, uint32_t v2, uint32_t m2) {
+        uint32_t keep = 0;
+        for (int b = 0; b < 4; b++) {
+          uint32_t bm = 0xFFu << (8 * b);
+          if ((mask & bm) && (m2 & bm) && ((val ^ v2) & bm) == 0) keep |= bm;
+        }
+        mask = keep;
+        val &= keep;
+      };
+      for (size_t wi = 0; wi < keyed.size(); wi++) {
+        const HgWindow &w = keyed[wi].second;
+        const HgFactor &f = db.factors[w.factor_off >> 8];
+        const int o = static_cast<int>(w.factor_off & 0xff);
+        uint32_t pv = 0, pm = 0, nv = 0, nm = 0;
         for (int b = 0; b < 4; b++) {
           int jp = o - 4 + b, jn = o + static_cast<int>(HG_WINDOW_BYTES) + b;
-          if (jp >= 0 && f.cmask[jp] != 0xFF) { pm &= ~(0xFFu << (8 * b)); pv &= pm; }
-          if (jn < static_cast<int>(f.len) && f.cmask[jn] != 0xFF) { nm &= ~(0xFFu << (8 * b)); nv &= nm; }
+          if (jp >= 0) { pv |= static_cast<uint32_t>(f.lit[jp]) << (8 * b); pm |= 0xFFu << (8 * b); }
+          if (jn < static_cast<int>(f.len)) { nv |= static_cast<uint32_t>(f.lit[jn]) << (8 * b); nm |= 0xFFu << (8 * b); }
         }
-      }
-      uint32_t sa = hg_slot(w.value, wa, byte_mask) >> 2, sb = hg_slot(w.value, wb, byte_mask) >> 2;
-      uint32_t fp = hg_hash_window(w.value);
-      for (uint32_t sl : {sa, sb}) {  // the entry for (sa, sb, fp) sits in exactly one of the two slots
-        if (owner[sl] < 0) continue;
-        const Entry &e = entries[owner[sl]];
-        if (e.fp != fp || e.sa != std::min(sa, sb) || e.sb != std::max(sa, sb)) continue;
-        HgFilterExt &x = db.ext[sl];
-        if (!seen[sl]) {
-          x = HgFilterExt{pv, pm, nv, nm};
-          slot_n16[sl] = next16_of[wi];
-          seen[sl] = true;
+        pv = (pv | fold) & pm;
+        nv = (nv | fold) & nm;
+        if (!fold) {  // case-insensitive letters cannot be compared exactly without folding: drop them
+          for (int b = 0; b < 4; b++) {
+            int jp = o - 4 + b, jn = o + static_cast<int>(HG_WINDOW_BYTES) + b;
+            if (jp >= 0 && f.cmask[jp] != 0xFF) { pm &= ~(0xFFu << (8 * b)); pv &= pm; }
+            if (jn < static_cast<int>(f.len) && f.cmask[jn] != 0xFF) { nm &= ~(0xFFu << (8 * b)); nv &= nm; }
+          }
+        }
+        // the slot keeps up to two values exactly, each with the agreement of the conditions of ITS windows
+        HgSlotInfo &info = db.ext[hg_slot(w.value, wa, byte_mask) >> 2];
+        HgFilterExt *x = nullptr;
+        bool fresh = false;
+        for (uint32_t i = 0; i < info.nvalues; i++)
+          if (info.value[i] == w.value) x = &info.cond[i];
+        if (!x && info.nvalues < 2) {
+          info.value[info.nvalues] = w.value;
+          x = &info.cond[info.nvalues++];
+          fresh = true;
+        }
+        if (!x) {
+          x = &info.rest;
+          fresh = !info.many;
+          info.many = 1;
+        }
+        if (fresh) {
+          *x = HgFilterExt{pv, pm, nv, nm};
         } else {
-          merge(x.pv, x.pm, pv, pm);
-          merge(x.nv, x.nm, nv, nm);
-          if (slot_n16[sl] != next16_of[wi]) slot_n16[sl] = 0;
+          merge(x->pv, x->pm, pv, pm);
+          merge(x->nv, x->nm, nv, nm);
         }
       }
     }
-    for (size_t sl = 0; sl < owner.size(); sl++)
-      if (owner[sl] >= 0) db.filter[sl] = entries[owner[sl]].fp;
   }
   db.filter_wide = 0;
   if (!placed) {
@@ -1133,7 +1152,7 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
         const uint32_t fp = entries[owner[cell]].fp;
         word = (cell & 1) ? ((word & 0x0000FFFFu) | (fp << 16)) : ((word & 0xFFFF0000u) | fp);
       }
-      db.ext.assign(1, HgFilterExt{0, 0, 0, 0});
+      db.ext.assign(1, HgSlotInfo{});
       db.filter_log2 = k;
       db.filter_wide = 1;
       db.weights_a = wa;

@@ -22,7 +22,7 @@ struct HgDb {
   uint32_t filter_log2 = HG_FILTER_MIN_LOG2;
   uint32_t filter_wide = 0;          // 1: two 16-bit fingerprints per slot, no neighbour conditions (large pattern sets)
   uint32_t weights_a = HG_SLOT_WEIGHT_CHOICES[0][0], weights_b = HG_SLOT_WEIGHT_CHOICES[0][1];
-  std::vector<HgFilterExt> ext;      // per filter slot: neighbour-dword conditions (second-level check)
+  std::vector<HgSlotInfo> ext;       // per filter slot: the window values in it and their neighbour-dword conditions (second-level check)
   std::vector<uint32_t> slow;        // indices of tier-1 (always-on) patterns
   uint32_t fold_mask = 0;            // 0x20202020 when any tier-0 pattern is case-insensitive
   uint32_t max_nw = 1;

@@ -33,12 +33,13 @@ constexpr uint32_t HG_WINDOW_BYTES = 4;
 constexpr uint32_t HG_WINDOW_MASK = HG_WINDOW_BYTES == 4 ? 0xFFFFFFFFu : 0x00FFFFFFu;
 constexpr uint32_t HG_FAST_MIN_FACTOR = HG_WINDOW_BYTES + 3;  // a window on every residue mod 4
 constexpr uint32_t HG_HASH_BITS = 18;       // v_dot4_u32_u8 of four bytes with weights < 256 fits 18 bits
-// Three byte-weighted sums of the (case-folded) window dword, one v_dot4_u32_u8 each:
+// Byte-weighted sums of the (case-folded) window dword, one v_dot4_u32_u8 each:
 //   hash C  -> bucket index of the window table in HBM, and (low 16 bits) the fingerprint
-//   hash A/B (weights are multiples of 4, so the sum is already the byte offset of a 4-byte slot) -> the two
-//   candidate slots of the window in the LDS filter (cuckoo placement: every window sits in exactly one of them).
-// A slot holds the window's full hash C (18 bits) in a dword: sub-dword LDS reads (ds_read_u16) measured ~8x
-// slower than ds_read_b32 on gfx950 for this random-access pattern.
+//   hash A  (weights are multiples of 4, so the sum is already the byte offset of a 4-byte slot) -> the window's slot
+//           in the LDS filter: ONE probe per text dword (two LDS reads per dword measured 5 % slower on the stream pass).
+// A slot word = care mask << 16 | fingerprint: windows that share a slot keep the fingerprint bits they agree on
+// (hg_slot_match), so a lookup can never miss a window; shared slots only admit more false positives, which the
+// second level and the verify pass remove.  (wide mode, large sets: hash A and B name two slots of two 16-bit cells)
 // (with 3-byte windows the weight of the dword's top byte is zero in all three sums: that byte is not part of the window)
 constexpr uint32_t HG_TOP_WEIGHT_MASK = HG_WINDOW_BYTES == 4 ? 0xFFFFFFFFu : 0x00FFFFFFu;
 constexpr uint32_t HG_HASH_WEIGHTS = 0xfbf1efe9u & HG_TOP_WEIGHT_MASK;  // C: 233, 239, 241, 251
@@ -103,6 +104,9 @@ HG_HD uint32_t hg_dot4(uint32_t v, uint32_t w) {
 HG_HD uint32_t hg_hash_window(uint32_t folded) { return hg_dot4(folded, HG_HASH_WEIGHTS); }
 // Byte offsets of the two candidate slots; byte_mask = (slots - 1) << 2.
 HG_HD uint32_t hg_slot(uint32_t folded, uint32_t weights, uint32_t byte_mask) { return hg_dot4(folded, weights) & byte_mask; }
+// Single-probe slot test: every fingerprint bit the slot cares about agrees with hash C (the mask has 16 bits, so the
+// upper bits of hash C drop out by themselves).  The empty slot 0xFFFFFFFF only admits fingerprint 0xFFFF.
+HG_HD bool hg_slot_match(uint32_t slot_word, uint32_t hash_c) { return ((hash_c ^ slot_word) & (slot_word >> 16)) == 0; }
 // Wide-mode slots (large pattern sets): one byte-weighted sum spans too few values for text over a small alphabet
 // (hex digits: ~9000 distinct sums), so each slot mixes the low bits of both sums, sum_x + (sum_y << 8).
 HG_HD uint32_t hg_slot_wide(uint32_t sum_x, uint32_t sum_y, uint32_t byte_mask) { return (sum_x + (sum_y << 8)) & byte_mask; }
@@ -127,6 +131,28 @@ HG_HD uint32_t hg_disc_bytes(uint32_t sel4) {
 }
 HG_HD uint32_t hg_disc_bucket(uint32_t h, uint32_t masked_dword) {
   return (h ^ (hg_dot4(masked_dword, HG_DISC_WEIGHTS_1) + (hg_dot4(masked_dword, HG_DISC_WEIGHTS_2) << 7))) & ((1u << HG_HASH_BITS) - 1u);
+}
+
+// Second level of a single-probe slot (64 B, HBM / L2): the window values that live in the slot, exactly, each with its
+// own neighbour conditions; a third and further value of a crowded slot share `rest` (byte-wise agreement).
+struct HgSlotInfo {
+  uint32_t value[2];    // folded window values
+  uint32_t nvalues;     // 0..2 of them valid
+  uint32_t many;        // more than two values map to the slot: any other dword is judged by `rest`
+  HgFilterExt cond[2];
+  HgFilterExt rest;
+};
+static_assert(sizeof(HgSlotInfo) == 64, "HgSlotInfo layout");
+// pm_keep / nm_keep: 0 where the caller has no left / right neighbour dword (condition skipped), else all ones.
+HG_HD bool hg_slot_pass(const HgSlotInfo &s, uint32_t folded, uint32_t prev_folded, uint32_t next_folded, uint32_t pm_keep, uint32_t nm_keep) {
+  HgFilterExt e;
+  if (s.nvalues > 0 && s.value[0] == folded) e = s.cond[0];
+  else if (s.nvalues > 1 && s.value[1] == folded) e = s.cond[1];
+  else if (s.many) e = s.rest;
+  else return false;
+  e.pm &= pm_keep;
+  e.nm &= nm_keep;
+  return hg_ext_pass(e, prev_folded, next_folded);
 }
 
 HG_HD bool hg_is_word(uint32_t b) {

@@ -31,7 +31,7 @@ struct HgStreamArgs {
   uint64_t nbytes, tile_begin, tile_end;  // the launch covers tiles [tile_begin, tile_end) of the text
   HgDbView db;
   const uint32_t *filter;  // 1 << filter_log2 window-hash slots
-  const HgFilterExt *ext;  // per slot: neighbour-dword conditions
+  const HgSlotInfo *ext;   // per slot: window values + neighbour-dword conditions
   HgTileSum *sums;
   HgCand *cands;         // nsegs x cand_seg_cap: one private segment per stream workgroup
   uint32_t *seg_count;   // candidates in each segment

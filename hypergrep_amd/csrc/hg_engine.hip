@@ -277,7 +277,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       if (const char *env = std::getenv("HG_STREAM_ROUND_ROBIN")) {
         if (std::atoi(env)) sa.span = 0;
       }
-      sa.ext = static_cast<const HgFilterExt *>(d_ext_);
+      sa.ext = static_cast<const HgSlotInfo *>(d_ext_);
       sa.sums = d_sums_;
       sa.cands = cands;
       sa.seg_count = seg_count;

@@ -26,11 +26,6 @@ constexpr int WG_WAVES = HG_STREAM_WG_WAVES;
 constexpr int WG_THREADS = WG_WAVES * 64;
 constexpr int ITERS = HG_TILE_BYTES / 1024;  // 1 KiB per wave-iteration
 
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane) {
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -94,12 +89,11 @@ struct Probe {
       if (ANY_ONLY) return (m0 || m1 || m2 || m3) ? 1u : 0u;
       return (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u) | (m3 ? 8u : 0u);
     }
-    const uint32_t ta0 = at(filter, a0 & BYTE_MASK), tb0 = at(filter, b0 & BYTE_MASK), ta1 = at(filter, a1 & BYTE_MASK), tb1 = at(filter, b1 & BYTE_MASK);
-    const uint32_t ta2 = at(filter, a2 & BYTE_MASK), tb2 = at(filter, b2 & BYTE_MASK), ta3 = at(filter, a3 & BYTE_MASK), tb3 = at(filter, b3 & BYTE_MASK);
-    if (ANY_ONLY) return (ta0 == c0 || tb0 == c0 || ta1 == c1 || tb1 == c1 || ta2 == c2 || tb2 == c2 || ta3 == c3 || tb3 == c3) ? 1u : 0u;
-    // bits 0..3: slot A of window k matched; bits 4..7: slot B
-    return (ta0 == c0 ? 1u : 0u) | (ta1 == c1 ? 2u : 0u) | (ta2 == c2 ? 4u : 0u) | (ta3 == c3 ? 8u : 0u) | (tb0 == c0 ? 16u : 0u) |
-           (tb1 == c1 ? 32u : 0u) | (tb2 == c2 ? 64u : 0u) | (tb3 == c3 ? 128u : 0u);
+    // single probe: the window's one slot must agree with hash C on every fingerprint bit the slot cares about
+    const uint32_t t0 = at(filter, a0 & BYTE_MASK), t1 = at(filter, a1 & BYTE_MASK), t2 = at(filter, a2 & BYTE_MASK), t3 = at(filter, a3 & BYTE_MASK);
+    const bool m0 = hg_slot_match(t0, c0), m1 = hg_slot_match(t1, c1), m2 = hg_slot_match(t2, c2), m3 = hg_slot_match(t3, c3);
+    if (ANY_ONLY) return (m0 || m1 || m2 || m3) ? 1u : 0u;
+    return (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u) | (m3 ? 8u : 0u);  // bit k: window k matched
   }
 };
 
@@ -108,7 +102,7 @@ struct StreamCtx {
   const uint4 *text16;
   uint64_t nbytes;
   const lds_u32 *filter;
-  const HgFilterExt *ext;      // the slots' neighbour conditions (HBM, L2-resident)
+  const HgSlotInfo *ext;       // the slots' window values and neighbour conditions (HBM, L2-resident)
   lds_u32 *queue;              // this wave's queue, one entry per 16-byte chunk whose first level matched: {chunk inside the tile | newlines of the
                                // tile before it << 10, tile, dword left of the chunk, dword right of it, the chunk} — the drain never re-reads the text
   lds_u32 *cand_count;         // the workgroup's candidate counter
@@ -181,25 +175,19 @@ __device__ __noinline__ void drain_batch(const StreamCtx cx, uint32_t first, uin
       constexpr uint32_t BYTE_MASK = ((1u << LOG2) - 1u) << 2;
       // one window per lane and trip (a chunk rarely has two first-level matches): the lanes' matches sit at different k,
       // and a loop over k would pay one round trip for the conditions per k
-      for (uint32_t todo = (l1 | (l1 >> 4)) & 15u; todo; todo &= todo - 1) {
+      for (uint32_t todo = l1 & 15u; todo; todo &= todo - 1) {
         const uint32_t k = __ffs(todo) - 1;
         const uint32_t wk = k == 0 ? cur.x : (k == 1 ? cur.y : (k == 2 ? cur.z : cur.w));
         const uint32_t wp = k == 0 ? left : (k == 1 ? cur.x : (k == 2 ? cur.y : cur.z));
         const uint32_t wn = k == 0 ? cur.y : (k == 1 ? cur.z : (k == 2 ? cur.w : right));
-        const bool ha = (l1 >> k) & 1u, hb = (l1 >> (k + 4)) & 1u;
         const uint32_t f = wk | cx.fold;
-        const uint32_t sa = (hg_dot4(f, cx.wa) & BYTE_MASK) >> 2, sb = (hg_dot4(f, cx.wb) & BYTE_MASK) >> 2;
         // read from HBM / L2: rare, and keeping the table out of LDS leaves room for more resident waves
-        HgFilterExt ea = cx.ext[sa], eb = cx.ext[sb];
-        if (k == 0 && !have_left) ea.pm = eb.pm = 0;
-        if (k == 3 && !have_right) {
-          ea.nm &= HG_WINDOW_BYTES == 4 ? 0u : 0xFFu;
-          eb.nm &= HG_WINDOW_BYTES == 4 ? 0u : 0xFFu;
-        }
+        const HgSlotInfo info = cx.ext[(hg_dot4(f, cx.wa) & BYTE_MASK) >> 2];
+        const uint32_t pm_keep = (k == 0 && !have_left) ? 0u : 0xFFFFFFFFu;
+        const uint32_t nm_keep = (k == 3 && !have_right) ? (HG_WINDOW_BYTES == 4 ? 0u : 0xFFu) : 0xFFFFFFFFu;
         const uint32_t prev = wp | cx.fold;
         const uint32_t next = (HG_WINDOW_BYTES == 4 ? wn : ((wk >> 24) | (wn << 8))) | cx.fold;
-        const bool oka = ha && hg_ext_pass(ea, prev, next), okb = hb && hg_ext_pass(eb, prev, next);
-        if (oka || okb) hits |= 1u << k;
+        if (hg_slot_pass(info, f & HG_WINDOW_MASK, prev, next, pm_keep, nm_keep)) hits |= 1u << k;
       }
     }
   }
@@ -384,7 +372,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_S
   cx.filter = (const lds_u32 *)(&s_mem[0]);
   cx.queue = (lds_u32 *)(&s_mem[FILTER_U4]) + wave * queue_cap(LOG2) * queue_entry_dw(LOG2);
   cx.cand_count = (lds_u32 *)(&s_mem[FILTER_U4 + QUEUE_U4]);
-  cx.ext = reinterpret_cast<const HgFilterExt *>(ext16);
+  cx.ext = reinterpret_cast<const HgSlotInfo *>(ext16);
   cx.seg = cands + static_cast<uint64_t>(blockIdx.x) * seg_cap;  // this workgroup's private output segment
   cx.seg_cap = seg_cap;
   cx.fold = fold;

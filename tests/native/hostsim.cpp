@@ -130,7 +130,7 @@ long hgsim_scan(void *h, const uint8_t *data, uint64_t nbytes, int buffer_size, 
         const uint32_t a = hg_dot4(folded, db->weights_a), b = hg_dot4(folded, db->weights_b);
         sla = hg_slot_wide(a, b, byte_mask) >> 2, slb = hg_slot_wide(b, a, byte_mask) >> 2;
       }
-      bool ha = db->filter[sla] == key0, hb = db->filter[slb] == key0;
+      bool ha = hg_slot_match(db->filter[sla], key0), hb = false;  // single probe (slot A)
       if (db->filter_wide) {
         const uint32_t fp = key0 & 0xFFFFu, ta = db->filter[sla], tb = db->filter[slb];
         ha = (ta & 0xFFFFu) == fp || (ta >> 16) == fp;
@@ -143,12 +143,8 @@ long hgsim_scan(void *h, const uint8_t *data, uint64_t nbytes, int buffer_size, 
         // the kernel cannot see across its 16 KiB tile edge or the first/last lane of a 1 KiB segment: treat as pass there
         const bool edge_prev = (pos % 1024) == 0, edge_next = (pos % 1024) == 1020;
         auto pass = [&](uint32_t sl) {
-          HgFilterExt e = db->ext[sl];
-          if (edge_prev) e.pm = 0;
-          if (edge_next) e.nm &= (HG_WINDOW_BYTES == 4 ? 0u : 0xFFu);  // the last lane sees at most its own dword's top byte
-          e.pv &= e.pm;
-          e.nv &= e.nm;
-          return hg_ext_pass(e, pf, nf);
+          // the last lane sees at most its own dword's top byte
+          return hg_slot_pass(db->ext[sl], folded, pf, nf, edge_prev ? 0u : 0xFFFFFFFFu, edge_next ? (HG_WINDOW_BYTES == 4 ? 0u : 0xFFu) : 0xFFFFFFFFu);
         };
         if (!db->filter_wide && !((ha && pass(sla)) || (hb && pass(slb)))) continue;
         level2_hits++;
