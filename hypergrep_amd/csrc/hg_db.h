@@ -106,7 +106,7 @@ HG_HD uint32_t hg_hash_window(uint32_t folded) { return hg_dot4(folded, HG_HASH_
 HG_HD uint32_t hg_slot(uint32_t folded, uint32_t weights, uint32_t byte_mask) { return hg_dot4(folded, weights) & byte_mask; }
 // Single-probe slot test: every fingerprint bit the slot cares about agrees with hash C (the mask has 16 bits, so the
 // upper bits of hash C drop out by themselves).  The empty slot 0xFFFFFFFF only admits fingerprint 0xFFFF.
-HG_HD bool hg_slot_match(uint32_t slot_word, uint32_t hash_c) { return ((hash_c ^ slot_word) & (slot_word >> 16)) == 0; }
+HG_HD bool hg_slot_match(uint32_t slot_word, uint32_t hash_c) { return (hash_c & (slot_word >> 16)) == (slot_word & 0xFFFFu); }
 // Wide-mode slots (large pattern sets): one byte-weighted sum spans too few values for text over a small alphabet
 // (hex digits: ~9000 distinct sums), so each slot mixes the low bits of both sums, sum_x + (sum_y << 8).
 HG_HD uint32_t hg_slot_wide(uint32_t sum_x, uint32_t sum_y, uint32_t byte_mask) { return (sum_x + (sum_y << 8)) & byte_mask; }

@@ -261,18 +261,19 @@ __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, 
       last_it = it;
       last_lane = 63u - __builtin_clzll(nlm);
     }
-    // newlines of the tile before this lane's chunk, cheap while every chunk of the iteration has at most one
-    uint32_t before, total;
+    // newlines of the iteration: a popcount of the ballot while every chunk has at most one (the per-lane prefix `before`,
+    // newlines of the tile before this lane's chunk, is only needed by lanes that queue their chunk)
+    uint32_t total, incl = 0;
     if (__builtin_expect(multi == 0, 1)) {
-      before = seen + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(nlm >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(nlm), 0u));
       total = __popcll(nlm);
     } else {
-      const uint32_t incl = wave_inclusive_scan(c, lane);
-      before = seen + incl - c;
+      incl = wave_inclusive_scan(c, lane);
       total = __builtin_amdgcn_readlane(incl, 63);
     }
     const uint64_t am = __builtin_amdgcn_ballot_w64(any);
     if (am) {  // remember the chunks; their windows are examined in batches of 64 (drain_batch)
+      const uint32_t before = multi == 0 ? seen + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(nlm >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(nlm), 0u))
+                                         : seen + incl - c;
       // the dwords next to the chunk, from the adjacent lanes (DPP wave shifts; the row's edge lanes get 0 and skip that condition)
       const uint32_t left = __builtin_amdgcn_update_dpp(0u, cur.w, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
       const uint32_t right = __builtin_amdgcn_update_dpp(0u, cur.x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
