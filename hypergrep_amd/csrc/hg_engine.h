@@ -21,6 +21,12 @@ struct HgDeferred {
 };
 enum { HG_CNT_CANDS = 0, HG_CNT_HITS = 1, HG_CNT_CAND_NEED = 2, HG_CNT_HIT_NEED = 3, HG_CNT_DEFER_NEED = 4, HG_CNT_WORDS = 8 };
 
+// Threads of a confirm block: its LDS (the per-lane follow tables of the one-word automata, 128 B per lane) decides how many
+// fit on a CU next to the stream pass.
+#ifndef HG_CONFIRM_THREADS
+#define HG_CONFIRM_THREADS 128
+#endif
+
 // Waves per stream workgroup (one 16 KiB tile per wave at a time); shared by the kernel and the grid sizing.
 #ifndef HG_STREAM_WG_WAVES
 #define HG_STREAM_WG_WAVES 8

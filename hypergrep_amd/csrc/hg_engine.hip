@@ -334,7 +334,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
           // the last chunk's side passes have the chip to themselves
           uint32_t per_cu = c + 1 == nchunks ? 6 : 2;
           if (const char *env = std::getenv("HG_CONFIRM_BLOCKS_PER_CU")) per_cu = static_cast<uint32_t>(std::max(1l, std::min(16l, std::strtol(env, nullptr, 10))));
-          const uint32_t mode_blocks = std::max<uint32_t>(HG_DEFER_SHARDS, static_cast<uint32_t>(num_cus_) * per_cu);
+          const uint32_t mode_blocks = std::max<uint32_t>(HG_DEFER_SHARDS, static_cast<uint32_t>(num_cus_) * per_cu * (256 / HG_CONFIRM_THREADS));  // per_cu counts 256 lanes
           confirm_blocks = std::max(mode_blocks * std::max(fast_modes, 1u), verify_blocks);  // the largest grid that stages hits
           ca.hit_seg_cap = hit_cap_ / confirm_blocks;
           ca.deferred = d_deferred_;
@@ -346,7 +346,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
           }
           HG_TRY(hipMemsetAsync(d_defer_count_, 0, HG_CONFIRM_MODES * HG_DEFER_SHARDS * 4, side), "memset deferred counts");
           hipLaunchKernelGGL(hg_verify_kernel, dim3(verify_blocks), dim3(256), 0, side, ca);
-          if (fast_modes) hipLaunchKernelGGL(hg_confirm_fast_kernel, dim3(mode_blocks * fast_modes), dim3(256), 0, side, ca, mode_blocks);
+          if (fast_modes) hipLaunchKernelGGL(hg_confirm_fast_kernel, dim3(mode_blocks * fast_modes), dim3(HG_CONFIRM_THREADS), 0, side, ca, mode_blocks);
           if (db_->n_confirm_mode[3]) hipLaunchKernelGGL(hg_confirm_generic_kernel, dim3(mode_blocks), dim3(256), 0, side, ca);
           HG_TRY(hipGetLastError(), "confirm launch");
         }

@@ -301,7 +301,10 @@ __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, 
     seen += total;
   };
 
-  constexpr int DEPTH = 3;  // 16-byte loads in flight per lane
+#ifndef HG_STREAM_DEPTH
+#define HG_STREAM_DEPTH 3
+#endif
+  constexpr int DEPTH = HG_STREAM_DEPTH;  // 16-byte loads in flight per lane
   if constexpr (FULL) {
     uint4 buf[DEPTH];
 #pragma unroll
@@ -724,7 +727,7 @@ __global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
 template <int MODE>
 __device__ __forceinline__ void confirm_body(const HgConfirmArgs &a, uint32_t vblock, uint32_t vgrid) {
   __shared__ uint32_t s_n, s_base;
-  __shared__ uint32_t s_follow[MODE == 1 ? 32 * 256 : 1];
+  __shared__ uint32_t s_follow[MODE == 1 ? 32 * HG_CONFIRM_THREADS : 1];
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
   const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
@@ -757,7 +760,7 @@ __device__ __forceinline__ void confirm_body(const HgConfirmArgs &a, uint32_t vb
 // Modes 0..2 in ONE launch (their items are few and each item is a chain of dependent loads: run back to back the three
 // passes cost three latency tails, side by side one): blocks [k * blocks_per_mode, (k+1) * blocks_per_mode) work on the
 // k-th mode present in the database.
-__global__ __launch_bounds__(256) void hg_confirm_fast_kernel(HgConfirmArgs a, uint32_t blocks_per_mode) {
+__global__ __launch_bounds__(HG_CONFIRM_THREADS) void hg_confirm_fast_kernel(HgConfirmArgs a, uint32_t blocks_per_mode) {
   const uint32_t k = blockIdx.x / blocks_per_mode, vblock = blockIdx.x % blocks_per_mode;  // block-uniform
   uint32_t mode = 0, seen = 0;
   for (uint32_t m = 0; m < 3; m++)
