@@ -11,6 +11,8 @@
 
 namespace hgdev {
 
+using lds_u32 = __attribute__((address_space(3))) uint32_t;
+
 __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *text, uint64_t off) {
   const uint32_t *p = reinterpret_cast<const uint32_t *>(text + (off & ~3ull));
   const uint32_t sh = static_cast<uint32_t>(off & 3u) * 8u;
@@ -324,6 +326,147 @@ __device__ __forceinline__ void confirm_ctx(const HgDbView &db, const uint8_t *t
   }
   if (first_to == HG_NONE32) {  // match ending exactly at the end of the scanned bytes
     const uint32_t *ac = acct + (pc * 5 + HG_NC_END) * NW;
+    uint32_t hit = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) hit |= S[w] & ac[w];
+    if (hit) first_to = static_cast<uint32_t>(z - a);
+  }
+  if (first_to != HG_NONE32) emit(line_no, first_to, a, static_cast<uint32_t>(z - a));
+}
+
+// confirm_simple with the pattern's tables staged by the wave in LDS (reach[256], follow[nodes]): no table traffic to HBM / L2.
+template <typename Emit>
+__device__ __forceinline__ void confirm_simple_tab(const uint8_t *text, uint64_t nbytes, const HgTileSum *sums, const HgTileBase *bases, uint64_t bs1, uint64_t pos,
+                                                   uint32_t rank, uint32_t init, uint32_t acc, const lds_u32 *reach, const lds_u32 *follow, Emit &&emit) {
+  const uint64_t t = pos >> HG_TILE_SHIFT, tile_start = t << HG_TILE_SHIFT;
+  const uint64_t s = rank == 0 ? bases[t].cs : line_start_in_tile(text, tile_start, pos);
+  const uint64_t k = (pos - s) / bs1;
+  const uint64_t ps = s + k * bs1;
+  const uint64_t line_no = hg_line_index(text, sums[t], bases[t], tile_start, rank, s, bs1, bs1 < HG_TILE_BYTES) + k;
+  const uint64_t limit = ps + bs1 < nbytes ? ps + bs1 : nbytes;
+
+
+  // leading NULs are skipped (hyperscanner.c:207-214): a = first non-NUL byte of the piece
+  uint64_t a = ps;
+  while (a < limit && text[a] == 0) a++;
+  if (a >= limit) return;  // empty or all-NUL piece
+
+  uint32_t S = 0, first_to = HG_NONE32;
+  uint64_t z = limit;
+  for (uint64_t chunk = a & ~15ull; chunk < limit; chunk += 16) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(text + chunk);
+    const uint32_t lo = chunk < a ? static_cast<uint32_t>(a - chunk) : 0u;
+    const uint32_t hi = limit - chunk < 16 ? static_cast<uint32_t>(limit - chunk) : 16u;
+    const uint32_t below_lo = (1u << lo) - 1u;
+    const uint32_t nl = eq_mask16(v, 0x0a0a0a0au) & ~below_lo, nul = eq_mask16(v, 0u) & ~below_lo;
+    // bytes [lo, end) of this chunk belong to the scanned line; the piece ends inside the chunk if stop
+    uint32_t end = hi;
+    bool stop = false;
+    const uint32_t stops = (nl | nul) & ((1u << hi) - 1u);
+    if (stops) {
+      const uint32_t e = __ffs(stops) - 1;
+      end = ((nl >> e) & 1u) ? e + 1 : e;  // a newline is part of the line, a NUL is not
+      stop = true;
+    }
+    if (first_to == HG_NONE32) {
+      uint32_t r[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) r[i] = reach[byte_of(v, i)];  // 16 independent loads
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        if (static_cast<uint32_t>(i) >= lo && static_cast<uint32_t>(i) < end && first_to == HG_NONE32) {
+          uint32_t T = init;
+          for (uint32_t x = S; x; x &= x - 1) T |= follow[__ffs(x) - 1];
+          S = T & r[i];
+          if (S & acc) first_to = static_cast<uint32_t>(chunk + i + 1 - a);
+        }
+      }
+    }
+    if (stop || hi < 16) {
+      z = chunk + end;
+      break;
+    }
+  }
+  if (first_to != HG_NONE32) emit(line_no, first_to, a, static_cast<uint32_t>(z - a));
+}
+
+// confirm_ctx with the pattern's tables staged by the wave in LDS.
+// (original:) Confirm one (candidate, pattern) for a SINGLEMATCH pattern with up to NW <= 2 state words and arbitrary boundary
+// conditions (^ $ \b ...): same chunked walk as confirm_simple, automaton tables read from HBM/L2 (the handful of
+// 4-byte lookups per text byte depend on the text only, except follow[], so they pipeline).
+template <int NW, typename Emit>
+__device__ __forceinline__ void confirm_ctx_tab(const uint8_t *text, uint64_t nbytes, const HgTileSum *sums, const HgTileBase *bases, uint64_t bs1, uint64_t pos,
+                                                uint32_t rank, const lds_u32 *reach, const lds_u32 *follow, const lds_u32 *init, const lds_u32 *amask, const lds_u32 *acct,
+                                                Emit &&emit) {
+  const uint64_t t = pos >> HG_TILE_SHIFT, tile_start = t << HG_TILE_SHIFT;
+  const uint64_t s = rank == 0 ? bases[t].cs : line_start_in_tile(text, tile_start, pos);
+  const uint64_t k = (pos - s) / bs1;
+  const uint64_t ps = s + k * bs1;
+  const uint64_t line_no = hg_line_index(text, sums[t], bases[t], tile_start, rank, s, bs1, bs1 < HG_TILE_BYTES) + k;
+  const uint64_t limit = ps + bs1 < nbytes ? ps + bs1 : nbytes;
+
+
+  uint64_t a = ps;
+  while (a < limit && text[a] == 0) a++;
+  if (a >= limit) return;
+
+  uint32_t S[NW], I[NW];
+#pragma unroll
+  for (int w = 0; w < NW; w++) { S[w] = 0; I[w] = init[w]; }
+  uint32_t pc = HG_PC_START, first_to = HG_NONE32;
+  uint64_t z = limit;
+  for (uint64_t chunk = a & ~15ull; chunk < limit; chunk += 16) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(text + chunk);
+    const uint32_t lo = chunk < a ? static_cast<uint32_t>(a - chunk) : 0u;
+    const uint32_t hi = limit - chunk < 16 ? static_cast<uint32_t>(limit - chunk) : 16u;
+    const uint32_t below_lo = (1u << lo) - 1u;
+    const uint32_t nl = eq_mask16(v, 0x0a0a0a0au) & ~below_lo, nul = eq_mask16(v, 0u) & ~below_lo;
+    uint32_t end = hi;
+    bool stop = false;
+    const uint32_t stops = (nl | nul) & ((1u << hi) - 1u);
+    if (stops) {
+      const uint32_t e = __ffs(stops) - 1;
+      end = ((nl >> e) & 1u) ? e + 1 : e;
+      stop = true;
+    }
+    if (first_to == HG_NONE32) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        if (static_cast<uint32_t>(i) >= lo && static_cast<uint32_t>(i) < end && first_to == HG_NONE32) {
+          const uint32_t c = byte_of(v, i);
+          // inside one line a '\n' is always the last scanned byte
+          const uint32_t cc = c == '\n' ? HG_NC_NLFINAL : (hg_is_word(c) ? HG_NC_WORD : HG_NC_OTHER);
+          const lds_u32 *ac = acct + (pc * 5 + cc) * NW, *am = amask + (pc * 4 + cc) * NW, *rc = reach + c * NW;
+          uint32_t hit = 0;
+#pragma unroll
+          for (int w = 0; w < NW; w++) hit |= S[w] & ac[w];
+          if (hit) {
+            first_to = static_cast<uint32_t>(chunk + i - a);
+          } else {
+            uint32_t T[NW];
+#pragma unroll
+            for (int w = 0; w < NW; w++) T[w] = I[w];
+#pragma unroll
+            for (int w = 0; w < NW; w++)
+              for (uint32_t x = S[w]; x; x &= x - 1) {
+                const lds_u32 *f = follow + (w * 32 + (__ffs(x) - 1)) * NW;
+#pragma unroll
+                for (int q = 0; q < NW; q++) T[q] |= f[q];
+              }
+#pragma unroll
+            for (int w = 0; w < NW; w++) S[w] = T[w] & rc[w] & am[w];
+            pc = hg_prev_ctx(c);
+          }
+        }
+      }
+    }
+    if (stop || hi < 16) {
+      z = chunk + end;
+      break;
+    }
+  }
+  if (first_to == HG_NONE32) {  // match ending exactly at the end of the scanned bytes
+    const lds_u32 *ac = acct + (pc * 5 + HG_NC_END) * NW;
     uint32_t hit = 0;
 #pragma unroll
     for (int w = 0; w < NW; w++) hit |= S[w] & ac[w];

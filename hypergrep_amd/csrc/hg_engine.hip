@@ -343,6 +343,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
           for (uint32_t m = 0, next = 0; m < HG_CONFIRM_MODES; m++) {
             ca.mode_present[m] = (db_->n_confirm_mode[m] && ((mode_mask >> m) & 1u)) ? 1 : 0;
             ca.list_of_mode[m] = db_->n_confirm_mode[m] ? next++ : 0;
+            ca.list_spread[m] = std::max<uint32_t>(1, HG_DEFER_SHARDS / std::max<uint32_t>(1, db_->n_confirm_mode[m]));
           }
           HG_TRY(hipMemsetAsync(d_defer_count_, 0, HG_CONFIRM_MODES * HG_DEFER_SHARDS * 4, side), "memset deferred counts");
           hipLaunchKernelGGL(hg_verify_kernel, dim3(verify_blocks), dim3(256), 0, side, ca);

@@ -612,7 +612,51 @@ __device__ __forceinline__ void flush_hits(const HgConfirmArgs &a, uint32_t *lds
 // routine, including the literal-only one, then runs over its own list with all lanes doing the same work.
 typedef uint32_t hg_u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
 
+// Automaton modes (1, 2): the confirm pass wants its lists keyed by pattern (confirm_tables_body), i.e. up to 128 lists per
+// block.  One global atomic per occurrence and list costs the pass 2 ms per 32 GiB, so the block stages these occurrences in
+// LDS and files them bin by bin: one global atomic per non-empty (mode, list) bin and flush.
+constexpr uint32_t VERIFY_STAGE_CAP = 768;  // 12 KiB
+struct VerifyStage {
+  HgDeferred item[VERIFY_STAGE_CAP];
+  uint8_t bin[VERIFY_STAGE_CAP];  // (mode - 1) * HG_DEFER_SHARDS + list
+  uint32_t n;
+  uint32_t bin_count[2 * HG_DEFER_SHARDS], bin_base[2 * HG_DEFER_SHARDS];
+};
+__device__ __forceinline__ void verify_stage_flush(const HgConfirmArgs &a, VerifyStage &st) {  // whole block
+  __syncthreads();
+  const uint32_t n = st.n < VERIFY_STAGE_CAP ? st.n : VERIFY_STAGE_CAP;
+  if (threadIdx.x < 2 * HG_DEFER_SHARDS) st.bin_count[threadIdx.x] = 0;
+  __syncthreads();
+  constexpr uint32_t PER_THREAD = (VERIFY_STAGE_CAP + 255) / 256;
+  uint32_t rank[PER_THREAD];
+#pragma unroll
+  for (uint32_t q = 0; q < PER_THREAD; q++) {
+    const uint32_t i = threadIdx.x + q * 256u;
+    rank[q] = i < n ? atomicAdd(&st.bin_count[st.bin[i]], 1u) : 0u;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * HG_DEFER_SHARDS && st.bin_count[threadIdx.x])
+    st.bin_base[threadIdx.x] = atomicAdd(&a.defer_count[HG_DEFER_SHARDS + threadIdx.x], st.bin_count[threadIdx.x]);  // modes 1, 2 follow mode 0's counters
+  __syncthreads();
+#pragma unroll
+  for (uint32_t q = 0; q < PER_THREAD; q++) {
+    const uint32_t i = threadIdx.x + q * 256u;
+    if (i < n) {
+      const uint32_t bin = st.bin[i], m = 1u + bin / HG_DEFER_SHARDS, list = bin % HG_DEFER_SHARDS;
+      const uint32_t slot = st.bin_base[bin] + rank[q];
+      if (slot < a.defer_shard_cap) a.deferred[(static_cast<uint64_t>(a.list_of_mode[m]) * HG_DEFER_SHARDS + list) * a.defer_shard_cap + slot] = st.item[i];
+      else atomicMax(&a.counters[HG_CNT_DEFER_NEED], slot + 1);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) st.n = 0;
+  __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
+  __shared__ VerifyStage s_stage;
+  if (threadIdx.x == 0) s_stage.n = 0;
+  __syncthreads();
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t seg = blockIdx.x / HG_CONFIRM_SPLIT, sub = blockIdx.x % HG_CONFIRM_SPLIT;
   const HgCand *cseg = a.cands + static_cast<uint64_t>(seg) * a.cand_seg_cap;
@@ -620,7 +664,12 @@ __global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
   const uint32_t shard = blockIdx.x % HG_DEFER_SHARDS;
   const uint32_t fold = a.db.fold_mask;
   const uint64_t readable = (a.nbytes + 15) & ~15ull;  // the text buffer can be read up to here
-  for (uint32_t base = (sub * 4u + wave) * 64u; base < n; base += HG_CONFIRM_SPLIT * 256u) {  // wave-uniform
+  for (uint32_t base0 = sub * 256u; base0 < n; base0 += HG_CONFIRM_SPLIT * 256u) {  // block-uniform: the staging flush is a block affair
+    __syncthreads();  // every wave has finished the previous round: the fill level is final ...
+    const uint32_t staged = s_stage.n;
+    __syncthreads();  // ... and has been read by all before anyone stages again
+    if (staged >= VERIFY_STAGE_CAP / 2) verify_stage_flush(a, s_stage);
+    const uint32_t base = base0 + wave * 64u;
     const uint32_t i = base + lane;
     HgCand c{0, 0, 0};
     uint32_t j0 = 0, cnt = 0, folded = 0;
@@ -705,6 +754,24 @@ __global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
       for (uint32_t m = 0; m < HG_CONFIRM_MODES; m++) {
         const uint64_t mm = __builtin_amdgcn_ballot_w64(ok && mode == m);
         if (!mm) continue;
+        if (m == 1 || m == 2) {  // staged, keyed by pattern (a pattern set with few such patterns spreads each over several lists)
+          uint32_t at0 = 0;
+          if (lane == 0) at0 = atomicAdd(&s_stage.n, static_cast<uint32_t>(__popcll(mm)));
+          at0 = __builtin_amdgcn_readfirstlane(at0);
+          if (ok && mode == m) {
+            const uint32_t at = at0 + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mm >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mm), 0u));
+            const uint32_t list = ((tag & (HG_MAX_PATTERNS - 1u)) * a.list_spread[m] + blockIdx.x % a.list_spread[m]) % HG_DEFER_SHARDS;
+            if (at < VERIFY_STAGE_CAP) {
+              s_stage.item[at] = HgDeferred{pos, tag, o_rank};
+              s_stage.bin[at] = static_cast<uint8_t>((m - 1u) * HG_DEFER_SHARDS + list);
+            } else {  // staging full (a wave met very large buckets): file this one directly
+              const uint32_t slot = atomicAdd(&a.defer_count[m * HG_DEFER_SHARDS + list], 1u);
+              if (slot < a.defer_shard_cap) a.deferred[(static_cast<uint64_t>(a.list_of_mode[m]) * HG_DEFER_SHARDS + list) * a.defer_shard_cap + slot] = HgDeferred{pos, tag, o_rank};
+              else atomicMax(&a.counters[HG_CNT_DEFER_NEED], slot + 1);
+            }
+          }
+          continue;
+        }
         uint32_t slot0 = 0;
         if (lane == 0) slot0 = atomicAdd(&a.defer_count[m * HG_DEFER_SHARDS + shard], static_cast<uint32_t>(__popcll(mm)));
         slot0 = __builtin_amdgcn_readfirstlane(slot0);
@@ -716,6 +783,7 @@ __global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
       }
     }
   }
+  verify_stage_flush(a, s_stage);
 }
 
 // Automaton passes over the deferred lists, one launch per confirm mode present in the database so that lanes of a
@@ -757,6 +825,88 @@ __device__ __forceinline__ void confirm_body(const HgConfirmArgs &a, uint32_t vb
   }
   flush_hits(a, &s_n, &s_base);
 }
+// Modes 1 and 2 (automata of one or two state words).  Run with the tables in HBM, one such occurrence costs hundreds of
+// scattered 4-byte loads (reach / follow / boundary masks per text byte) and the pass is bound by memory requests.  Here
+// the lists are keyed by pattern (the verify pass files an occurrence under pattern % HG_DEFER_SHARDS), each block takes an
+// equal slice of the concatenated lists, and a wave stages the tables of ONE pattern at a time in LDS (<= 3 KiB) and runs
+// the lanes whose occurrence belongs to it: a slice holds a handful of patterns, and the only HBM traffic left is the text.
+constexpr uint32_t CT_REACH = 0, CT_FOLLOW = 512, CT_INIT = 640, CT_AMASK = 644, CT_ACC = 676, CT_WORDS = 768;  // dword offsets in a wave's table area
+template <int MODE>
+__device__ __forceinline__ void confirm_tables_body(const HgConfirmArgs &a, uint32_t vblock, uint32_t vgrid) {
+  __shared__ uint32_t s_n, s_base;
+  __shared__ __attribute__((aligned(16))) uint32_t s_tab[(HG_CONFIRM_THREADS / 64) * CT_WORDS];
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
+  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n};
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  hgdev::lds_u32 *tab = (hgdev::lds_u32 *)(&s_tab[0]) + wave * CT_WORDS;
+  // this block's slice [lo, hi) of the concatenation of the HG_DEFER_SHARDS lists (lane s holds list s)
+  static_assert(HG_DEFER_SHARDS == 64, "one list per lane");
+  uint32_t cnt = a.defer_count[MODE * HG_DEFER_SHARDS + lane];
+  if (cnt > a.defer_shard_cap) cnt = a.defer_shard_cap;
+  const uint32_t incl = wave_inclusive_scan(cnt, lane), start = incl - cnt;
+  const uint32_t total = __shfl(incl, 63, 64);
+  const uint32_t lo = static_cast<uint32_t>(static_cast<uint64_t>(total) * vblock / vgrid), hi = static_cast<uint32_t>(static_cast<uint64_t>(total) * (vblock + 1) / vgrid);
+  const HgDeferred *lists = a.deferred + static_cast<uint64_t>(a.list_of_mode[MODE]) * HG_DEFER_SHARDS * a.defer_shard_cap;
+  for (uint32_t g0 = lo + wave * 64u; g0 < hi; g0 += HG_CONFIRM_THREADS) {  // wave-uniform
+    const uint32_t g = g0 + lane;
+    // list holding item g: the last list whose exclusive prefix is <= g
+    uint32_t list = 0;
+#pragma unroll
+    for (uint32_t step = 32; step; step >>= 1) {
+      const uint32_t probe = list + step;
+      const uint32_t sp = __shfl(start, probe & 63u, 64);
+      if (probe < 64u && sp <= g) list = probe;
+    }
+    const uint32_t l_start = __shfl(start, list, 64);
+    const bool valid = g < hi;
+    HgDeferred d{0, 0, 0};
+    if (valid) d = lists[static_cast<uint64_t>(list) * a.defer_shard_cap + (g - l_start)];
+    const uint32_t pattern = d.pattern & (HG_MAX_PATTERNS - 1u);
+    for (uint64_t todo = __builtin_amdgcn_ballot_w64(valid); todo;) {  // one pattern at a time
+      const uint32_t pat = __builtin_amdgcn_readlane(pattern, __builtin_ctzll(todo));
+      const bool mine = valid && pattern == pat;
+      todo &= ~__builtin_amdgcn_ballot_w64(mine);
+      const HgPattern &p = a.db.patterns[pat];  // wave-uniform: scalar loads
+      const uint32_t nw = MODE == 1 ? 1u : p.nw;
+      {  // stage the tables: reach[256][nw] as 16-byte pieces, the small ones a dword per lane
+        const uint4 *rsrc = reinterpret_cast<const uint4 *>(a.db.pool + p.reach_off);
+        uint4 r0 = rsrc[lane];
+        tab[CT_REACH + 4 * lane + 0] = r0.x; tab[CT_REACH + 4 * lane + 1] = r0.y; tab[CT_REACH + 4 * lane + 2] = r0.z; tab[CT_REACH + 4 * lane + 3] = r0.w;
+        if (nw == 2) {
+          uint4 r1 = rsrc[64 + lane];
+          tab[CT_REACH + 256 + 4 * lane + 0] = r1.x; tab[CT_REACH + 256 + 4 * lane + 1] = r1.y; tab[CT_REACH + 256 + 4 * lane + 2] = r1.z; tab[CT_REACH + 256 + 4 * lane + 3] = r1.w;
+        }
+        const uint32_t nfollow = p.nnodes * nw;  // <= 128
+        for (uint32_t i = lane; i < nfollow; i += 64) tab[CT_FOLLOW + i] = a.db.pool[p.follow_off + i];
+        if (MODE == 2) {
+          if (lane < nw) tab[CT_INIT + lane] = a.db.pool[p.init_off + lane];
+          if (lane < 16 * nw) tab[CT_AMASK + lane] = a.db.pool[p.amask_off + lane];
+          if (lane < 20 * nw) tab[CT_ACC + lane] = a.db.pool[p.acc_off + lane];
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (mine) {
+        const uint32_t id = p.id;
+        auto emit = [&](uint64_t line_no, uint32_t to, uint64_t start_, uint32_t len) { sink.push(line_no, id, to, start_, len, pat); };
+        if (MODE == 1) {
+          hgdev::confirm_simple_tab(a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, d.rank, p.init_word, p.acc_all, tab + CT_REACH, tab + CT_FOLLOW, emit);
+        } else if (nw == 1) {
+          hgdev::confirm_ctx_tab<1>(a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, d.rank, tab + CT_REACH, tab + CT_FOLLOW, tab + CT_INIT, tab + CT_AMASK, tab + CT_ACC,
+                                    emit);
+        } else {
+          hgdev::confirm_ctx_tab<2>(a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, d.rank, tab + CT_REACH, tab + CT_FOLLOW, tab + CT_INIT, tab + CT_AMASK, tab + CT_ACC,
+                                    emit);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();  // the next pattern's tables overwrite this one's
+    }
+  }
+  flush_hits(a, &s_n, &s_base);
+}
+
 // Modes 0..2 in ONE launch (their items are few and each item is a chain of dependent loads: run back to back the three
 // passes cost three latency tails, side by side one): blocks [k * blocks_per_mode, (k+1) * blocks_per_mode) work on the
 // k-th mode present in the database.
@@ -766,8 +916,8 @@ __global__ __launch_bounds__(HG_CONFIRM_THREADS) void hg_confirm_fast_kernel(HgC
   for (uint32_t m = 0; m < 3; m++)
     if (a.mode_present[m] && seen++ == k) mode = m;
   if (mode == 0) confirm_body<0>(a, vblock, blocks_per_mode);
-  else if (mode == 1) confirm_body<1>(a, vblock, blocks_per_mode);
-  else confirm_body<2>(a, vblock, blocks_per_mode);
+  else if (mode == 1) confirm_tables_body<1>(a, vblock, blocks_per_mode);
+  else confirm_tables_body<2>(a, vblock, blocks_per_mode);
 }
 __global__ __launch_bounds__(256) void hg_confirm_generic_kernel(HgConfirmArgs a) { confirm_body<3>(a, blockIdx.x, gridDim.x); }
 
