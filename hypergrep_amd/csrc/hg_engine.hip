@@ -330,9 +330,9 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
           uint32_t fast_modes = 0, mode_mask = 0xF;
           if (const char *env = std::getenv("HG_DEBUG_CONFIRM_MODES")) mode_mask = static_cast<uint32_t>(std::strtoul(env, nullptr, 0));  // profiling aid: results are incomplete
           for (uint32_t m = 0; m < 3; m++) fast_modes += (db_->n_confirm_mode[m] && ((mode_mask >> m) & 1u)) ? 1 : 0;
-          // few, long-lived blocks per confirm routine: next to the stream pass only ~2 of them fit on a CU at a time;
+          // few, long-lived blocks per confirm routine (in units of 256 lanes per CU; 3 measured best next to the stream pass);
           // the last chunk's side passes have the chip to themselves
-          uint32_t per_cu = c + 1 == nchunks ? 6 : 2;
+          uint32_t per_cu = c + 1 == nchunks ? 6 : 3;
           if (const char *env = std::getenv("HG_CONFIRM_BLOCKS_PER_CU")) per_cu = static_cast<uint32_t>(std::max(1l, std::min(16l, std::strtol(env, nullptr, 10))));
           const uint32_t mode_blocks = std::max<uint32_t>(HG_DEFER_SHARDS, static_cast<uint32_t>(num_cus_) * per_cu * (256 / HG_CONFIRM_THREADS));  // per_cu counts 256 lanes
           confirm_blocks = std::max(mode_blocks * std::max(fast_modes, 1u), verify_blocks);  // the largest grid that stages hits
