@@ -139,6 +139,9 @@ class HgScanner {
   static constexpr int kMaxChunks = 16;
   hipStream_t side_stream_ = nullptr;
   hipEvent_t ev_k1_begin_[kMaxChunks] = {}, ev_k1_end_[kMaxChunks] = {}, ev_side_done_[kMaxChunks] = {};
+  hipStream_t fin_stream_ = nullptr;   // early sort of the first chunks' hits (chunked pipeline)
+  hipEvent_t ev_fin_done_ = nullptr;
+  uint32_t *h_early_ = nullptr;        // pinned: counters after the last-but-one chunk's side passes
   uint32_t *d_seg_count2_ = nullptr;  // second set for double buffering
   HgCand *d_cands2_ = nullptr;
 };

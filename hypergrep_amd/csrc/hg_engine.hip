@@ -27,6 +27,7 @@ __global__ void hg_block_mark_kernel(HgConfirmArgs a, uint32_t *pattern_flags);
 __global__ void hg_block_scan_kernel(HgConfirmArgs a, const uint32_t *pattern_flags);
 __global__ void hg_key_kernel(const HgHit *hits, const HgHitAux *aux, const HgPattern *patterns, uint32_t n, uint64_t *key, uint32_t *idx);
 __global__ void hg_line_key_kernel(const HgHit *hits, const uint32_t *perm, uint32_t n, uint64_t *key);
+__global__ void hg_offset_kernel(uint32_t *idx, uint32_t n, uint32_t add);
 __global__ void hg_key_packed_kernel(const HgHit *hits, const HgHitAux *aux, const HgPattern *patterns, uint32_t n, uint32_t id_bits, uint32_t to_bits,
                                      uint64_t *key, uint32_t *idx);
 __global__ void hg_keep_kernel(const HgHit *hits, const HgHitAux *aux, const uint32_t *perm, const HgPattern *patterns, uint32_t n, uint8_t *keep);
@@ -113,6 +114,9 @@ int HgScanner::create(const HgDb *db, int device, HgScanner **out, std::string *
   HG_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_final_), sizeof(HgTileBase)), "alloc pinned");
   for (auto &ev : s->ev_) HG_TRY(hipEventCreate(&ev), "hipEventCreate");
   HG_TRY(hipStreamCreateWithFlags(&s->side_stream_, hipStreamNonBlocking), "hipStreamCreate");
+  HG_TRY(hipStreamCreateWithFlags(&s->fin_stream_, hipStreamNonBlocking), "hipStreamCreate");
+  HG_TRY(hipEventCreateWithFlags(&s->ev_fin_done_, hipEventDisableTiming), "hipEventCreate");
+  HG_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_early_), HG_CNT_WORDS * 4), "alloc pinned");
   for (int i = 0; i < kMaxChunks; i++) {
     HG_TRY(hipEventCreate(&s->ev_k1_begin_[i]), "hipEventCreate");
     HG_TRY(hipEventCreate(&s->ev_k1_end_[i]), "hipEventCreate");
@@ -140,6 +144,9 @@ HgScanner::~HgScanner() {
     if (ev_side_done_[i]) (void)hipEventDestroy(ev_side_done_[i]);
   }
   if (side_stream_) (void)hipStreamDestroy(side_stream_);
+  if (fin_stream_) (void)hipStreamDestroy(fin_stream_);
+  if (ev_fin_done_) (void)hipEventDestroy(ev_fin_done_);
+  if (h_early_) (void)hipHostFree(h_early_);
 }
 
 int HgScanner::alloc_cands(uint64_t n) {
@@ -174,7 +181,9 @@ int HgScanner::alloc_hits(uint64_t n64) {
   size_t t1 = 0, t2 = 0;
   (void)rocprim::radix_sort_pairs(nullptr, t1, d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, n, 0, 64, hipStream_t(nullptr));
   (void)rocprim::exclusive_scan(nullptr, t2, d_keep_, d_perm_a_, 0u, n, rocprim::plus<uint32_t>(), hipStream_t(nullptr));
-  size_t need = std::max(t1, t2) + 256;
+  size_t t3 = 0;
+  (void)rocprim::merge(nullptr, t3, d_key_a_, d_key_a_, d_key_b_, d_perm_a_, d_perm_a_, d_perm_b_, n, n, rocprim::less<uint64_t>(), hipStream_t(nullptr));
+  size_t need = std::max(std::max(t1, t2), t3) + 256;
   if (need > temp_bytes_) {
     if (d_temp_) (void)hipFree(d_temp_);
     d_temp_ = nullptr;
@@ -358,6 +367,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
           HG_TRY(hipGetLastError(), "hg_always_on_kernel launch");
         }
       }
+      if (piped && c + 2 == nchunks) HG_TRY(hipMemcpyAsync(h_early_, d_counters_, HG_CNT_WORDS * 4, hipMemcpyDeviceToHost, side), "copy counters");
       if (piped) HG_TRY(hipEventRecord(ev_side_done_[c], side), "event");
     }
     if (piped) HG_TRY(hipStreamWaitEvent(stream, ev_side_done_[nchunks - 1], 0), "stream wait");
@@ -369,7 +379,26 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
     h_final_->L = line_base;
   }
   HG_TRY(hipMemcpyAsync(h_counters_, d_counters_, HG_CNT_WORDS * 4, hipMemcpyDeviceToHost, stream), "copy counters");
+  // Chunked pipeline: while the last chunk is still streaming, the hits of all earlier chunks are final.  They are keyed and
+  // sorted now, on a third stream; after the last chunk only its own hits are sorted and the two runs merged.  The key layout
+  // must be fixed before the line count is known: the line field is sized for one line per byte.
+  const uint32_t id_bits = bits_for(static_cast<uint64_t>(db_->max_id) + 1), to_bits = bits_for(bs1 + 1);
+  const uint32_t line_bits_bound = bits_for(line_base + nbytes + 1);
+  uint32_t n_early = 0;
+  if (piped && line_bits_bound + id_bits + to_bits + 1 <= 64) {
+    HG_TRY(hipEventSynchronize(ev_side_done_[nchunks - 2]), "event sync (early hits)");
+    const bool clean = !h_early_[HG_CNT_HIT_NEED] && !h_early_[HG_CNT_CAND_NEED] && !h_early_[HG_CNT_DEFER_NEED] && h_early_[HG_CNT_HITS] <= hit_cap_;
+    if (clean && h_early_[HG_CNT_HITS] >= 4096) {
+      n_early = h_early_[HG_CNT_HITS];
+      const HgPattern *pats = static_cast<const HgPattern *>(d_patterns_);
+      hipLaunchKernelGGL(hg_key_packed_kernel, dim3((n_early + 255) / 256), dim3(256), 0, fin_stream_, d_hits_raw_, d_aux_raw_, pats, n_early, id_bits, to_bits, d_key_a_, d_perm_a_);
+      size_t tb = temp_bytes_;
+      HG_TRY(rocprim::radix_sort_pairs(d_temp_, tb, d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, n_early, 0, line_bits_bound + id_bits + to_bits + 1, fin_stream_), "radix sort (early)");
+      HG_TRY(hipEventRecord(ev_fin_done_, fin_stream_), "event");
+    }
+  }
   HG_TRY(hipStreamSynchronize(stream), "stream sync (scan kernels)");
+  if (n_early) HG_TRY(hipStreamWaitEvent(stream, ev_fin_done_, 0), "stream wait");
   if (piped) {
     for (uint32_t c = 0; c < nchunks; c++) {
       float ms = 0;
@@ -383,6 +412,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   const uint64_t defer_need = h_counters_[HG_CNT_DEFER_NEED];
   if (cand_need || defer_need || hit_need || n_raw > hit_cap_) {
     // a private segment (or the compact hit array) was too small: grow and let the caller repeat the pass
+    if (n_early) HG_TRY(hipStreamSynchronize(fin_stream_), "stream sync (early sort)");  // before its buffers are replaced
     if (cand_need || defer_need) {
       uint64_t want = std::max<uint64_t>((cand_need + cand_need / 4 + 64) * wgs, (defer_need + defer_need / 4 + 64) * HG_DEFER_SHARDS);
       want = std::max<uint64_t>(want, static_cast<uint64_t>(cand_cap_) * 2);
@@ -414,11 +444,26 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
     const HgPattern *pats = static_cast<const HgPattern *>(d_patterns_);
     uint32_t blocks = (n + 255) / 256;
     // order by (line, id, to, single-after-multi): one radix sort over exactly the bits in use when they fit in 64, else two
-    const uint32_t line_bits = bits_for(line_base + n_pieces + 1), id_bits = bits_for(static_cast<uint64_t>(db_->max_id) + 1), to_bits = bits_for(bs1 + 1);
+    const uint32_t line_bits = bits_for(line_base + n_pieces + 1);
     const uint32_t *perm = nullptr;
     uint32_t *pos = nullptr;
     size_t tb = temp_bytes_;
-    if (line_bits + id_bits + to_bits + 1 <= 64) {
+    if (n_early) {
+      // [0, n_early) is sorted in key_b / perm_b already: sort the last chunk's hits behind it and merge the two runs
+      const uint32_t n_late = n - n_early;
+      if (n_late) {
+        hipLaunchKernelGGL(hg_key_packed_kernel, dim3((n_late + 255) / 256), dim3(256), 0, stream, d_hits_raw_ + n_early, d_aux_raw_ + n_early, pats, n_late, id_bits, to_bits,
+                           d_key_a_ + n_early, d_perm_a_ + n_early);
+        hipLaunchKernelGGL(hg_offset_kernel, dim3((n_late + 255) / 256), dim3(256), 0, stream, d_perm_a_ + n_early, n_late, n_early);
+        HG_TRY(rocprim::radix_sort_pairs(d_temp_, tb, d_key_a_ + n_early, d_key_b_ + n_early, d_perm_a_ + n_early, d_perm_b_ + n_early, n_late, 0,
+                                         line_bits_bound + id_bits + to_bits + 1, stream), "radix sort (last chunk)");
+      }
+      tb = temp_bytes_;
+      // (keys 1, keys 2, keys out, values 1, values 2, values out)
+      HG_TRY(rocprim::merge(d_temp_, tb, d_key_b_, d_key_b_ + n_early, d_key_a_, d_perm_b_, d_perm_b_ + n_early, d_perm_a_, n_early, n_late, rocprim::less<uint64_t>(), stream), "merge");
+      perm = d_perm_a_;
+      pos = d_perm_b_;
+    } else if (line_bits + id_bits + to_bits + 1 <= 64) {
       hipLaunchKernelGGL(hg_key_packed_kernel, dim3(blocks), dim3(256), 0, stream, d_hits_raw_, d_aux_raw_, pats, n, id_bits, to_bits, d_key_a_, d_perm_a_);
       HG_TRY(rocprim::radix_sort_pairs(d_temp_, tb, d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, n, 0, line_bits + id_bits + to_bits + 1, stream), "radix sort");
       perm = d_perm_b_;

@@ -989,6 +989,11 @@ __global__ void hg_line_key_kernel(const HgHit *hits, const uint32_t *perm, uint
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) key[i] = hits[perm[i]].line_no;
 }
+// indices of a later run are positions in the whole raw array
+__global__ void hg_offset_kernel(uint32_t *idx, uint32_t n, uint32_t add) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) idx[i] += add;
+}
 __global__ void hg_key_packed_kernel(const HgHit *hits, const HgHitAux *aux, const HgPattern *patterns, uint32_t n, uint32_t id_bits, uint32_t to_bits,
                                      uint64_t *key, uint32_t *idx) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
