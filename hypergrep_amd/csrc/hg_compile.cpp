@@ -986,8 +986,7 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
     if (db.windows2.empty()) db.windows2.push_back(HgWindow{0, 0});
   }
 
-  // LDS filter: cuckoo placement of the hash of each distinct window value.  Every value owns exactly one of its
-  // two slots, so a lookup that reads both slots can never miss it.
+  // LDS filter over the distinct window values (single-probe slots below; two-slot cells in wide mode).
   std::vector<uint32_t> values;
   for (auto &kw : keyed) values.push_back(kw.second.value);
   std::sort(values.begin(), values.end());

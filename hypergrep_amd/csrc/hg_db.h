@@ -2,7 +2,7 @@
 //
 // Replaces what hs_compile_multi builds for the reference (hypergrep/lib/c/hyperscanner.c:126-142):
 // instead of Hyperscan's opaque bytecode the database is a set of flat arrays that the engine uploads
-// to HBM once; the 32 KiB window bitmap is the only part staged in LDS by the streaming kernel.
+// to HBM once; the window filter (8-128 KiB, normally 16 KiB) is the only part staged in LDS by the streaming kernel.
 #pragma once
 #include <cstdint>
 
@@ -43,7 +43,8 @@ constexpr uint32_t HG_HASH_BITS = 18;       // v_dot4_u32_u8 of four bytes with 
 // (with 3-byte windows the weight of the dword's top byte is zero in all three sums: that byte is not part of the window)
 constexpr uint32_t HG_TOP_WEIGHT_MASK = HG_WINDOW_BYTES == 4 ? 0xFFFFFFFFu : 0x00FFFFFFu;
 constexpr uint32_t HG_HASH_WEIGHTS = 0xfbf1efe9u & HG_TOP_WEIGHT_MASK;  // C: 233, 239, 241, 251
-// A / B weight pairs the compiler tries in turn until the cuckoo placement succeeds (bytes are multiples of 4
+// Candidate weight vectors (A and B of each pair: the single-probe filter takes whichever spreads the windows best, wide
+// mode uses a pair for its two slots; bytes are multiples of 4
 // and deliberately not in arithmetic progression, so that no small byte difference cancels in both sums).
 constexpr uint32_t HG_SLOT_WEIGHT_CHOICES[][2] = {
     {0x2cec94fcu & HG_TOP_WEIGHT_MASK, 0xbc34f474u & HG_TOP_WEIGHT_MASK},  // A: 252,148,236,44   B: 116,244,52,188

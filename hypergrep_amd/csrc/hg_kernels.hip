@@ -2,7 +2,7 @@
 // (hypergrep/lib/c/hyperscanner.c:198-226: gzgets -> strlen -> hs_scan -> hs_callback per line) with
 //
 //   hg_stream_kernel      one pass over the text in HBM: 16 B per lane coalesced loads, per-dword window
-//                         fingerprint (v_dot4_u32_u8) probed in an LDS cuckoo filter, exact newline counts
+//                         fingerprint (v_dot4_u32_u8) probed in the single-probe LDS filter, exact newline counts
 //                         per 16 KiB wave tile; chunks with a fingerprint match are queued in LDS and examined
 //                         64 at a time (neighbour conditions), survivors go to the workgroup's candidate segment
 //   hg_tile_*             3-launch scan of the tile newline summaries -> global piece numbers
