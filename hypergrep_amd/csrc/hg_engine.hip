@@ -252,8 +252,14 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       const long v = std::strtol(env, nullptr, 10);
       if (v >= 1 && v <= stream_wgs_per_cu_) per_cu = static_cast<uint32_t>(v);
     }
-    wgs = static_cast<uint32_t>(std::min<uint64_t>((std::min<uint64_t>(chunk_tiles, ntiles) + STREAM_WG_WAVES - 1) / STREAM_WG_WAVES,
-                                                   std::min<uint64_t>(static_cast<uint64_t>(num_cus_) * per_cu, max_segs_)));
+    auto grid_for = [&](uint32_t wgs_per_cu) {
+      return static_cast<uint32_t>(std::min<uint64_t>((std::min<uint64_t>(chunk_tiles, ntiles) + STREAM_WG_WAVES - 1) / STREAM_WG_WAVES,
+                                                      std::min<uint64_t>(static_cast<uint64_t>(num_cus_) * wgs_per_cu, max_segs_)));
+    };
+    const uint32_t wgs_shared = grid_for(per_cu);  // next to the side passes of the previous chunk
+    // the first chunk streams alone: every workgroup slot (unless the grid was fixed by hand)
+    const uint32_t wgs_alone = std::getenv("HG_STREAM_WGS_PER_CU") ? wgs_shared : grid_for(static_cast<uint32_t>(stream_wgs_per_cu_));
+    wgs = std::max(wgs_shared, wgs_alone);  // sizes the regrowth of the candidate segments
     hipStream_t side = piped ? side_stream_ : stream;
     HgTileBase init{0, line_base};
     *h_final_ = init;
@@ -264,6 +270,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
     }
     for (uint32_t c = 0; c < nchunks; c++) {
       const uint64_t t0 = static_cast<uint64_t>(c) * chunk_tiles, t1 = std::min<uint64_t>(t0 + chunk_tiles, ntiles);
+      const uint32_t wgs_c = c == 0 ? wgs_alone : wgs_shared;
       const uint32_t set = piped ? (c & 1u) : 0u;
       HgCand *cands = set ? d_cands2_ : d_cands_;
       uint32_t *seg_count = set ? d_seg_count2_ : d_seg_count_;
@@ -282,7 +289,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       sa.filter_wide = db_->filter_wide;
       // every workgroup streams its own consecutive range of tiles: same HBM rate as dealing tiles round-robin (measured),
       // and the verify / confirm passes then find neighbouring lines in neighbouring lanes (confirm 1.8 -> 1.5 ms per 32 GiB)
-      sa.span = static_cast<uint32_t>(((t1 - t0 + wgs - 1) / wgs + STREAM_WG_WAVES - 1) / STREAM_WG_WAVES * STREAM_WG_WAVES);
+      sa.span = static_cast<uint32_t>(((t1 - t0 + wgs_c - 1) / wgs_c + STREAM_WG_WAVES - 1) / STREAM_WG_WAVES * STREAM_WG_WAVES);
       if (const char *env = std::getenv("HG_STREAM_ROUND_ROBIN")) {
         if (std::atoi(env)) sa.span = 0;
       }
@@ -290,10 +297,10 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       sa.sums = d_sums_;
       sa.cands = cands;
       sa.seg_count = seg_count;
-      sa.cand_seg_cap = cand_cap_ / wgs;
+      sa.cand_seg_cap = cand_cap_ / wgs_c;
       sa.counters = d_counters_;
       HG_TRY(hipEventRecord(piped ? ev_k1_begin_[c] : ev_[1], stream), "event");
-      hg_launch_stream(sa, wgs, stream);
+      hg_launch_stream(sa, wgs_c, stream);
       HG_TRY(hipGetLastError(), "hg_stream_kernel launch");
       HG_TRY(hipEventRecord(piped ? ev_k1_end_[c] : ev_[2], stream), "event");
       if (piped) HG_TRY(hipStreamWaitEvent(side, ev_k1_end_[c], 0), "stream wait");
@@ -318,7 +325,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       ca.counters = d_counters_;
       if (block_mode) {
         HG_TRY(hipMemsetAsync(d_pflags_, 0, db_->patterns.size() * 4, side), "memset pattern flags");
-        if (has_anchored) hipLaunchKernelGGL(hg_block_mark_kernel, dim3(wgs), dim3(256), 0, side, ca, d_pflags_);
+        if (has_anchored) hipLaunchKernelGGL(hg_block_mark_kernel, dim3(wgs_c), dim3(256), 0, side, ca, d_pflags_);
         always_blocks = static_cast<uint32_t>((db_->patterns.size() + 255) / 256);
         ca.hit_seg_cap = hit_cap_ / always_blocks;
         hipLaunchKernelGGL(hg_block_scan_kernel, dim3(always_blocks), dim3(256), 0, side, ca, d_pflags_);
@@ -335,7 +342,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
         hipLaunchKernelGGL(hg_tile_apply_kernel, dim3(nblocks), dim3(256), 0, side, d_sums_, t0, t1, bs1, d_block_base_, d_bases_);
         HG_TRY(hipGetLastError(), "tile scan launch");
         if (has_anchored) {
-          const uint32_t verify_blocks = wgs * HG_CONFIRM_SPLIT;  // HG_CONFIRM_SPLIT blocks share candidate segment b
+          const uint32_t verify_blocks = wgs_c * HG_CONFIRM_SPLIT;  // HG_CONFIRM_SPLIT blocks share candidate segment b
           uint32_t fast_modes = 0, mode_mask = 0xF;
           if (const char *env = std::getenv("HG_DEBUG_CONFIRM_MODES")) mode_mask = static_cast<uint32_t>(std::strtoul(env, nullptr, 0));  // profiling aid: results are incomplete
           for (uint32_t m = 0; m < 3; m++) fast_modes += (db_->n_confirm_mode[m] && ((mode_mask >> m) & 1u)) ? 1 : 0;
