@@ -477,3 +477,25 @@ def test_full_size_properties_32gib(torch_cuda, monkeypatch):
     want, nl = oracle_hits(host[:head_n], patterns, ids=ids)
     got = [h[:3] for h in sc.hits(limit=len(want) + 16) if h[0] < nl]
     assert sorted(got) == [w[:3] for w in want]
+
+
+def test_crowded_filter_slots_and_large_buckets(torch_cuda):
+    """Stress of the paths a small pattern set never reaches: (a) 3000 literals -> slots shared by three and more windows
+    (HgSlotInfo.many, weak care masks); (b) 200 automaton patterns behind ONE shared literal, dense in the text -> buckets of
+    200 pairs per candidate, the verify pass's LDS stage overflows into its direct path, pattern-keyed lists fill unevenly."""
+    rng = random.Random(2024)
+    alphabet = "abcdefghijklmnopqrstuvwxyz0123456789_"
+    lits = sorted({"".join(rng.choice(alphabet) for _ in range(rng.randint(8, 14))) for _ in range(3000)})
+    data = _log_text(rng, 8000, lits, p_hit=0.5)
+    ids = list(range(len(lits)))
+    want, nlines = oracle_hits(data, lits, ids=ids)
+    got, stats = gpu_scan_buffer(torch_cuda, data, lits, ids=ids)
+    assert stats.n_lines == nlines and got == want and len(want) > 3000
+
+    pats = [f"shared_literal_x{i % 10}[0-9]{{1,3}}(?:a{i}b|c{i}d)" for i in range(200)]
+    needles = [f"shared_literal_x{i % 10}{rng.randint(0, 999)}{'a%db' % i if i % 2 else 'c%dd' % i}" for i in range(200)] + ["shared_literal_x3", "shared_literal_x77zz"]
+    data = _log_text(rng, 20000, needles, p_hit=0.95)
+    ids = list(range(len(pats)))
+    want, nlines = oracle_hits(data, pats, ids=ids)
+    got, stats = gpu_scan_buffer(torch_cuda, data, pats, ids=ids)
+    assert stats.n_lines == nlines and got == want and len(want) > 10000
