@@ -51,6 +51,58 @@ void hgsim_info(void *h, uint32_t *out) {  // npatterns, nfactors, nwindows, nsl
   out[4] = db->fold_mask;
   out[5] = db->max_nw;
 }
+static HgDbView view_of(HgDb *db);
+// Invariants of the compiled prefilter, checked on the tables themselves (no text): every window of every literal
+//  (1) passes the first level at its own slot, (2) passes the second level when the literal's own bytes surround it,
+//  (3) is found by the verify pass's discriminated bucket lookup when the literal itself is the text.
+// Returns the number of violations; out[0] = filter log2, out[1] = wide, out[2] = slots holding more than two values.
+uint32_t hgsim_selfcheck(void *h, uint32_t *out) {
+  HgDb *db = static_cast<HgDb *>(h);
+  const HgDbView v = view_of(db);
+  uint32_t bad = 0, many = 0;
+  const uint32_t byte_mask = ((1u << db->filter_log2) - 1u) << 2;
+  if (!db->filter_wide)
+    for (const HgSlotInfo &s : db->ext) many += s.many ? 1 : 0;
+  for (size_t wi = 0; wi < db->windows.size() && db->nreal_factors; wi++) {
+    const HgWindow &w = db->windows[wi];
+    const HgFactor &f = db->factors[w.factor_off >> 8];
+    const uint32_t off = w.factor_off & 0xff;
+    const uint32_t key = hg_hash_window(w.value);
+    // the literal as a text of its own, lower-cased where it is case-insensitive (what folding maps both cases to)
+    std::vector<uint8_t> text(f.lit, f.lit + f.len);
+    auto dword_at = [&](int64_t p) {
+      uint32_t x = 0;
+      for (int b = 0; b < 4; b++)
+        if (p + b >= 0 && p + b < static_cast<int64_t>(f.len)) x |= static_cast<uint32_t>(text[p + b]) << (8 * b);
+      return x;
+    };
+    if (db->filter_wide) {
+      const uint32_t a = hg_dot4(w.value, db->weights_a), b = hg_dot4(w.value, db->weights_b), fp = key & 0xFFFFu;
+      const uint32_t ta = db->filter[hg_slot_wide(a, b, byte_mask) >> 2], tb = db->filter[hg_slot_wide(b, a, byte_mask) >> 2];
+      if (!((ta & 0xFFFFu) == fp || (ta >> 16) == fp || (tb & 0xFFFFu) == fp || (tb >> 16) == fp)) bad++;
+    } else {
+      const uint32_t sl = hg_slot(w.value, db->weights_a, byte_mask) >> 2;
+      if (!hg_slot_match(db->filter[sl], key)) bad++;
+      const uint32_t prev = dword_at(static_cast<int64_t>(off) - 4) | db->fold_mask, next = dword_at(static_cast<int64_t>(off) + HG_WINDOW_BYTES) | db->fold_mask;
+      // bytes outside the literal are unknown in a real text: try both extremes
+      for (uint32_t fill : {0u, 0xFFFFFFFFu}) {
+        uint32_t p2 = prev, n2 = next;
+        for (int b = 0; b < 4; b++) {
+          if (static_cast<int>(off) - 4 + b < 0) p2 = (p2 & ~(0xFFu << (8 * b))) | (fill & (0xFFu << (8 * b)));
+          if (off + HG_WINDOW_BYTES + b >= f.len) n2 = (n2 & ~(0xFFu << (8 * b))) | (fill & (0xFFu << (8 * b)));
+        }
+        if (!hg_slot_pass(db->ext[sl], w.value, p2 | db->fold_mask, n2 | db->fold_mask, 0xFFFFFFFFu, 0xFFFFFFFFu)) bad++;
+      }
+    }
+    uint32_t j0, j1;
+    hg_disc_range(v, text.data(), f.len, off, w.value, &j0, &j1);
+    bool found = false;
+    for (uint32_t j = j0; j < j1; j++) found = found || (db->windows2[j].value == w.value && db->windows2[j].factor_off == w.factor_off);
+    if (!found) bad++;
+  }
+  if (out) { out[0] = db->filter_log2; out[1] = db->filter_wide; out[2] = many; }
+  return bad;
+}
 uint32_t hgsim_pattern_tier(void *h, uint32_t i) { return static_cast<HgDb *>(h)->patterns[i].tier; }
 uint32_t hgsim_pattern_nodes(void *h, uint32_t i) { return static_cast<HgDb *>(h)->patterns[i].nnodes; }
 

@@ -3,6 +3,7 @@ replayed on the host by tests/native/hostsim.cpp and compared with the oracle.""
 from __future__ import annotations
 
 import random
+import re
 
 import pytest
 
@@ -216,3 +217,23 @@ def test_golden_plumbing_vectors_through_device_logic():
         got, _, _ = sim_hits(data, v["patterns"], flags=kw.get("flags"), ids=kw.get("ids"), buffer_size=kw.get("buffer_size", 262140))
         want = sorted((r[0], r[1], base64.b64decode(r[2])) for r in v["rows"])
         assert sorted((h[0], h[1], data[h[3]:h[3] + h[4]]) for h in got) == want, v["name"]
+
+
+@pytest.mark.parametrize("n_literals, seed", [(40, 1), (600, 2), (3000, 3), (9000, 4)])
+def test_prefilter_tables_never_lose_a_window(n_literals, seed):
+    """Every window of every literal passes its filter slot, its slot's second level with the literal's own neighbours,
+    and the verify pass's discriminated bucket — before and after tuning on text that contains look-alikes."""
+    rng = random.Random(seed)
+    alphabet = "abcdefghijklmnopqrstuvwxyz0123456789_-=/"
+    lits = sorted({"".join(rng.choice(alphabet) for _ in range(rng.randint(7, 20))) for _ in range(n_literals)})
+    pats = [re.escape(l) for l in lits] + ["user=[a-z0-9_]{4,12} status=5[0-9]{2}", "(?i)CaseLess_Literal_[0-9]+", "prefix_(?:alpha|beta|gamma)_suffix"]
+    db = hgsim_py.Db(pats, ids=list(range(len(pats))))
+    assert db.ok(), db.error
+    first = db.selfcheck()
+    assert first["violations"] == 0
+    sample = ("\n".join(rng.choice(lits)[:-1] + "x status=200 user=abcd" for _ in range(4000)) + "\n").encode()
+    assert db.tune(sample) == 0
+    second = db.selfcheck()
+    assert second["violations"] == 0
+    if n_literals >= 3000:
+        assert second["wide"] or second["crowded_slots"] >= 0  # large sets: either mode is fine, the invariants are what counts
