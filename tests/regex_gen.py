@@ -80,3 +80,53 @@ def random_text(rng: random.Random, nlines: int, maxlen: int = 24, final_newline
     if final_newline and nlines:
         data += b"\n"
     return data
+
+
+# ---- patterns anchored by a long literal (the prefilter tier), with strings that match them and near-misses
+_PARTS = [
+    ("[0-9]{1,3}", lambda r: "".join(r.choice("0123456789") for _ in range(r.randint(1, 3)))),
+    ("[a-f]+", lambda r: "".join(r.choice("abcdef") for _ in range(r.randint(1, 6)))),
+    ("(?:foo|ba+r)", lambda r: r.choice(["foo", "bar", "baaar"])),
+    ("x?", lambda r: r.choice(["", "x"])),
+    (".{0,4}", lambda r: "".join(r.choice("qrs tuv") for _ in range(r.randint(0, 4)))),
+    ("[A-Z_]{2,5}", lambda r: "".join(r.choice("ABCXYZ_") for _ in range(r.randint(2, 5)))),
+    ("\\b", lambda r: ""),
+    (" +", lambda r: " " * r.randint(1, 3)),
+    ("(?:ab|cd){1,2}", lambda r: "".join(r.choice(["ab", "cd"]) for _ in range(r.randint(1, 2)))),
+    ("[^,;]", lambda r: r.choice("abz09 _")),
+]
+
+
+def anchored_pattern(rng):
+    """(pattern, sampler): a random expression around a literal of 8..16 bytes; sampler(rng) returns a string that
+    usually matches (boundary parts may veto it) or, one time in three, a near-miss of it."""
+    lit = "".join(rng.choice("ghijklmnop_-=:") for _ in range(rng.randint(8, 16)))
+    before = [rng.choice(_PARTS) for _ in range(rng.randint(0, 2))]
+    after = [rng.choice(_PARTS) for _ in range(rng.randint(0, 2))]
+    tail = rng.choice(["", "", "$", "\\b"])
+    esc = "".join("\\" + c if c in "-=:" else c for c in lit)
+    pattern = "".join(p for p, _ in before) + esc + "".join(p for p, _ in after) + tail
+
+    def sample(r):
+        s = "".join(f(r) for _, f in before) + lit + "".join(f(r) for _, f in after)
+        roll = r.random()
+        if roll < 0.15:  # break the literal
+            i = r.randrange(len(s))
+            s = s[:i] + r.choice("XY7") + s[i + 1:]
+        elif roll < 0.3:  # cut it short
+            s = s[: r.randrange(1, len(s))]
+        return s
+
+    return pattern, sample
+
+
+def anchored_text(rng, samplers, nlines):
+    filler = ["alpha", "beta", "status=200", "GET", "x", "foo", "bar7", "1234", "ZZ_TOP", "ab", "cd", ""]
+    lines = []
+    for _ in range(nlines):
+        toks = [rng.choice(filler) for _ in range(rng.randint(0, 6))]
+        for _ in range(rng.choice([0, 1, 1, 2])):
+            toks.insert(rng.randint(0, len(toks)), rng.choice(samplers)(rng))
+        sep = rng.choice([" ", " ", "", ","])
+        lines.append(sep.join(toks))
+    return ("\n".join(lines) + "\n").encode()

@@ -237,3 +237,20 @@ def test_prefilter_tables_never_lose_a_window(n_literals, seed):
     assert second["violations"] == 0
     if n_literals >= 3000:
         assert second["wide"] or second["crowded_slots"] >= 0  # large sets: either mode is fine, the invariants are what counts
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_literal_anchored_patterns_match_oracle(seed):
+    """Random expressions around a long literal (prefilter tier, every confirm mode) on text made of their own matches
+    and near-misses: compiler + scalar device logic vs the oracle."""
+    rng = random.Random(4100 + seed)
+    pairs = [regex_gen.anchored_pattern(rng) for _ in range(rng.randint(3, 10))]
+    pats = [p for p, _ in pairs]
+    flags = [rng.choice([14, 14, 15, 6, 10]) for _ in pats]
+    ids = [rng.randint(0, 3) for _ in pats]
+    assert oracle_py.check_patterns(pats, flags=flags) == 0, pats
+    data = regex_gen.anchored_text(rng, [s for _, s in pairs], 600)
+    want, _ = oracle_hits(data, pats, flags, ids)
+    got, _, db = sim_hits(data, pats, flags, ids)
+    assert got == want, (pats, flags, ids)
+    assert len(want) > 50 and db.info()["nslow"] == 0

@@ -499,3 +499,21 @@ def test_crowded_filter_slots_and_large_buckets(torch_cuda):
     want, nlines = oracle_hits(data, pats, ids=ids)
     got, stats = gpu_scan_buffer(torch_cuda, data, pats, ids=ids)
     assert stats.n_lines == nlines and got == want and len(want) > 10000
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_literal_anchored_patterns_match_oracle(torch_cuda, seed):
+    """Random expressions around a long literal: every one goes through the prefilter, the verify pass and one of the
+    confirm routines (literal-only, one-word, two-word / boundary, generic for all-matches mode)."""
+    rng = random.Random(7300 + seed)
+    pairs = [regex_gen.anchored_pattern(rng) for _ in range(rng.randint(3, 24))]
+    pats = [p for p, _ in pairs]
+    flags = [rng.choice([14, 14, 15, 6, 10]) for _ in pats]
+    ids = [rng.randint(0, 5) for _ in pats]
+    assert oracle_py.check_patterns(pats, flags=flags) == 0, pats
+    data = regex_gen.anchored_text(rng, [s for _, s in pairs], 6000)
+    want, nlines = oracle_hits(data, pats, flags, ids)
+    got, stats = gpu_scan_buffer(torch_cuda, data, pats, flags, ids)
+    assert stats.n_lines == nlines
+    assert got == want, (pats, flags, ids)
+    assert len(want) > 500
