@@ -298,6 +298,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       sa.cands = cands;
       sa.seg_count = seg_count;
       sa.cand_seg_cap = cand_cap_ / wgs_c;
+      sa.alone = (c == 0 && wgs_c == wgs_alone && !std::getenv("HG_STREAM_WGS_PER_CU")) ? 1u : 0u;
       sa.counters = d_counters_;
       HG_TRY(hipEventRecord(piped ? ev_k1_begin_[c] : ev_[1], stream), "event");
       hg_launch_stream(sa, wgs_c, stream);

@@ -217,7 +217,7 @@ __device__ __noinline__ void drain_batch(const StreamCtx cx, uint32_t first, uin
 
 // One tile.  FULL: the tile lies entirely inside the text (no bounds checks on the hot path).
 // qn: entries in the wave's queue (wave-uniform, carried from tile to tile).
-template <int LOG2, bool WIDE, bool FULL>
+template <int LOG2, bool WIDE, bool FULL, int DEPTH>
 __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, HgTileSum *__restrict__ sums, uint32_t lane, uint32_t &qn) {
   const uint4 *__restrict__ text16 = cx.text16;
   const uint64_t nbytes = cx.nbytes;
@@ -301,10 +301,7 @@ __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, 
     seen += total;
   };
 
-#ifndef HG_STREAM_DEPTH
-#define HG_STREAM_DEPTH 3
-#endif
-  constexpr int DEPTH = HG_STREAM_DEPTH;  // 16-byte loads in flight per lane
+  // DEPTH: 16-byte loads in flight per lane
   if constexpr (FULL) {
     uint4 buf[DEPTH];
 #pragma unroll
@@ -353,7 +350,9 @@ __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, 
 #ifndef HG_STREAM_WAVES
 #define HG_STREAM_WAVES 6
 #endif
-template <int LOG2, bool WIDE>
+// DEPTH: 16-byte loads in flight per lane.  Measured: with three workgroups resident per CU one is best (more thrashes), with
+// two (next to the side passes of the chunked pipeline) three.
+template <int LOG2, bool WIDE, int DEPTH>
 __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_STREAM_WAVES, 8))) void hg_stream_kernel(const uint4 *__restrict__ text16, uint64_t nbytes, uint64_t tile_begin, uint64_t tile_end,
                                                                   const uint4 *__restrict__ filter16, const uint4 *__restrict__ ext16,
                                                                   uint32_t fold, uint32_t wa, uint32_t wb, HgTileSum *__restrict__ sums,
@@ -396,8 +395,8 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_S
   }
   uint32_t qn = 0;
   for (uint64_t tile = tile_first; tile < tile_last; tile += tile_stride) {
-    if (tile < full_tiles) stream_tile<LOG2, WIDE, true>(cx, tile, sums, lane, qn);
-    else stream_tile<LOG2, WIDE, false>(cx, tile, sums, lane, qn);
+    if (tile < full_tiles) stream_tile<LOG2, WIDE, true, DEPTH>(cx, tile, sums, lane, qn);
+    else stream_tile<LOG2, WIDE, false, DEPTH>(cx, tile, sums, lane, qn);
   }
   if (qn) drain_batch<LOG2, WIDE>(cx, 0u, qn, lane);
   __syncthreads();
@@ -411,18 +410,24 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_S
 
 // Host-side launcher: picks the instantiation for the database's filter size / mode.
 namespace {
-template <int L, bool W>
-void launch_one(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
+template <int L, bool W, int D>
+void launch_depth(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
   const uint4 *t = reinterpret_cast<const uint4 *>(a.text);
   const uint4 *f = reinterpret_cast<const uint4 *>(a.filter);
   const uint4 *x = reinterpret_cast<const uint4 *>(a.ext);
-  hipLaunchKernelGGL((hg_stream_kernel<L, W>), dim3(grid), dim3(WG_THREADS), 0, stream, t, a.nbytes, a.tile_begin, a.tile_end, f, x, a.db.fold_mask,
+  hipLaunchKernelGGL((hg_stream_kernel<L, W, D>), dim3(grid), dim3(WG_THREADS), 0, stream, t, a.nbytes, a.tile_begin, a.tile_end, f, x, a.db.fold_mask,
                      a.weights_a, a.weights_b, a.sums, a.cands, a.cand_seg_cap, a.seg_count, a.counters, a.span);
+}
+template <int L, bool W>
+void launch_one(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
+  // filters up to 16 KiB leave room for three workgroups per CU: a launch that has the chip to itself prefetches one chunk ahead
+  if (!W && L <= 12 && a.alone) launch_depth<L, W, (!W && L <= 12) ? 1 : 3>(a, grid, stream);
+  else launch_depth<L, W, 3>(a, grid, stream);
 }
 template <int L, bool W>
 int blocks_one() {
   int n = 0;
-  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (hg_stream_kernel<L, W>), WG_THREADS, 0);
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (hg_stream_kernel<L, W, 3>), WG_THREADS, 0);
   return n > 0 ? n : 1;
 }
 }  // namespace
