@@ -171,7 +171,9 @@ def parallel_grep(  # pylint: disable=too-many-arguments,too-many-locals
         "no_messages": no_messages,
         "max_match_count": max_match_count,
     }
-    workers = max(1, min(len(files), max((os.cpu_count() or 2) - 1, 1)))
+    # the reference runs one job per core; here a job is a GPU scan with its own reader threads and pinned buffers, so a
+    # handful in flight already keeps every GPU of the node busy
+    workers = max(1, min(len(files), max((os.cpu_count() or 2) - 1, 1), 16))
     if use_multithreading:
         pool: concurrent.futures.Executor = concurrent.futures.ThreadPoolExecutor(max_workers=workers)
     else:
