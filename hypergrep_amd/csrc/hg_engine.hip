@@ -463,8 +463,9 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
         hipLaunchKernelGGL(hg_key_packed_kernel, dim3((n_late + 255) / 256), dim3(256), 0, stream, d_hits_raw_ + n_early, d_aux_raw_ + n_early, pats, n_late, id_bits, to_bits,
                            d_key_a_ + n_early, d_perm_a_ + n_early);
         hipLaunchKernelGGL(hg_offset_kernel, dim3((n_late + 255) / 256), dim3(256), 0, stream, d_perm_a_ + n_early, n_late, n_early);
+        // same key layout as the early run, but by now the line count is known: the bits above it are zero in every key
         HG_TRY(rocprim::radix_sort_pairs(d_temp_, tb, d_key_a_ + n_early, d_key_b_ + n_early, d_perm_a_ + n_early, d_perm_b_ + n_early, n_late, 0,
-                                         line_bits_bound + id_bits + to_bits + 1, stream), "radix sort (last chunk)");
+                                         std::min(line_bits, line_bits_bound) + id_bits + to_bits + 1, stream), "radix sort (last chunk)");
       }
       tb = temp_bytes_;
       // (keys 1, keys 2, keys out, values 1, values 2, values out)
