@@ -2,8 +2,7 @@
 // reference routine in hg_core.h (hg_confirm), which stays in use for multi-word / all-matches patterns and is what the
 // host tests replay; here the same work is arranged for memory latency:
 //   * the line is located and scanned in aligned 16-byte chunks (SWAR newline / NUL detection), four loads in flight,
-//   * for "simple" patterns (one state word, no boundary conditions) the automaton step needs only reach[c],
-//     whose 16 loads per chunk are independent, and the follow table, which is staged in LDS per lane.
+//   * the automaton tables of the pattern a wave is working on are staged in LDS (hg_kernels.hip, confirm_tables_body).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -189,154 +188,11 @@ __device__ __forceinline__ void confirm_literal(const uint8_t *text, uint64_t nb
   emit(pv.line_no, static_cast<uint32_t>(from - a), a, static_cast<uint32_t>(z - a));
 }
 
-// Confirm one (candidate, pattern) for a "simple" SINGLEMATCH pattern.  follow_lds: this lane's private LDS slot
-// (entries interleaved by lane: index v * 64).  Reports at most one hit: the smallest match end offset.
+// Confirm one (candidate, pattern) for a "simple" SINGLEMATCH pattern (one state word, no boundary conditions).  reach[256] /
+// follow[nodes]: the pattern's tables, staged by the wave in LDS (no table traffic to HBM / L2; the 16 reach lookups of a chunk
+// are independent).  Reports at most one hit: the smallest match end offset.
 template <typename Emit>
-__device__ __forceinline__ void confirm_simple(const HgDbView &db, const uint8_t *text, uint64_t nbytes, const HgTileSum *sums, const HgTileBase *bases,
-                                               uint64_t bs1, uint64_t pos, const HgPattern &p, uint32_t rank, uint32_t *follow_lds, Emit &&emit) {
-  const uint64_t t = pos >> HG_TILE_SHIFT, tile_start = t << HG_TILE_SHIFT;
-  const uint64_t s = rank == 0 ? bases[t].cs : line_start_in_tile(text, tile_start, pos);
-  const uint64_t k = (pos - s) / bs1;
-  const uint64_t ps = s + k * bs1;
-  const uint64_t line_no = hg_line_index(text, sums[t], bases[t], tile_start, rank, s, bs1, bs1 < HG_TILE_BYTES) + k;
-  const uint64_t limit = ps + bs1 < nbytes ? ps + bs1 : nbytes;
-
-  const uint32_t *reach = db.pool + p.reach_off, *follow = db.pool + p.follow_off;
-  for (uint32_t v = 0; v < p.nnodes; v++) follow_lds[v * 64] = follow[v];
-  const uint32_t init = p.init_word, acc = p.acc_all;
-
-  // leading NULs are skipped (hyperscanner.c:207-214): a = first non-NUL byte of the piece
-  uint64_t a = ps;
-  while (a < limit && text[a] == 0) a++;
-  if (a >= limit) return;  // empty or all-NUL piece
-
-  uint32_t S = 0, first_to = HG_NONE32;
-  uint64_t z = limit;
-  for (uint64_t chunk = a & ~15ull; chunk < limit; chunk += 16) {
-    const uint4 v = *reinterpret_cast<const uint4 *>(text + chunk);
-    const uint32_t lo = chunk < a ? static_cast<uint32_t>(a - chunk) : 0u;
-    const uint32_t hi = limit - chunk < 16 ? static_cast<uint32_t>(limit - chunk) : 16u;
-    const uint32_t below_lo = (1u << lo) - 1u;
-    const uint32_t nl = eq_mask16(v, 0x0a0a0a0au) & ~below_lo, nul = eq_mask16(v, 0u) & ~below_lo;
-    // bytes [lo, end) of this chunk belong to the scanned line; the piece ends inside the chunk if stop
-    uint32_t end = hi;
-    bool stop = false;
-    const uint32_t stops = (nl | nul) & ((1u << hi) - 1u);
-    if (stops) {
-      const uint32_t e = __ffs(stops) - 1;
-      end = ((nl >> e) & 1u) ? e + 1 : e;  // a newline is part of the line, a NUL is not
-      stop = true;
-    }
-    if (first_to == HG_NONE32) {
-      uint32_t r[16];
-#pragma unroll
-      for (int i = 0; i < 16; i++) r[i] = reach[byte_of(v, i)];  // 16 independent loads
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        if (static_cast<uint32_t>(i) >= lo && static_cast<uint32_t>(i) < end && first_to == HG_NONE32) {
-          uint32_t T = init;
-          for (uint32_t x = S; x; x &= x - 1) T |= follow_lds[(__ffs(x) - 1) * 64];
-          S = T & r[i];
-          if (S & acc) first_to = static_cast<uint32_t>(chunk + i + 1 - a);
-        }
-      }
-    }
-    if (stop || hi < 16) {
-      z = chunk + end;
-      break;
-    }
-  }
-  if (first_to != HG_NONE32) emit(line_no, first_to, a, static_cast<uint32_t>(z - a));
-}
-
-// Confirm one (candidate, pattern) for a SINGLEMATCH pattern with up to NW <= 2 state words and arbitrary boundary
-// conditions (^ $ \b ...): same chunked walk as confirm_simple, automaton tables read from HBM/L2 (the handful of
-// 4-byte lookups per text byte depend on the text only, except follow[], so they pipeline).
-template <int NW, typename Emit>
-__device__ __forceinline__ void confirm_ctx(const HgDbView &db, const uint8_t *text, uint64_t nbytes, const HgTileSum *sums, const HgTileBase *bases,
-                                            uint64_t bs1, uint64_t pos, const HgPattern &p, uint32_t rank, Emit &&emit) {
-  const uint64_t t = pos >> HG_TILE_SHIFT, tile_start = t << HG_TILE_SHIFT;
-  const uint64_t s = rank == 0 ? bases[t].cs : line_start_in_tile(text, tile_start, pos);
-  const uint64_t k = (pos - s) / bs1;
-  const uint64_t ps = s + k * bs1;
-  const uint64_t line_no = hg_line_index(text, sums[t], bases[t], tile_start, rank, s, bs1, bs1 < HG_TILE_BYTES) + k;
-  const uint64_t limit = ps + bs1 < nbytes ? ps + bs1 : nbytes;
-
-  const uint32_t *reach = db.pool + p.reach_off, *follow = db.pool + p.follow_off, *init = db.pool + p.init_off;
-  const uint32_t *amask = db.pool + p.amask_off, *acct = db.pool + p.acc_off;
-
-  uint64_t a = ps;
-  while (a < limit && text[a] == 0) a++;
-  if (a >= limit) return;
-
-  uint32_t S[NW], I[NW];
-#pragma unroll
-  for (int w = 0; w < NW; w++) { S[w] = 0; I[w] = init[w]; }
-  uint32_t pc = HG_PC_START, first_to = HG_NONE32;
-  uint64_t z = limit;
-  for (uint64_t chunk = a & ~15ull; chunk < limit; chunk += 16) {
-    const uint4 v = *reinterpret_cast<const uint4 *>(text + chunk);
-    const uint32_t lo = chunk < a ? static_cast<uint32_t>(a - chunk) : 0u;
-    const uint32_t hi = limit - chunk < 16 ? static_cast<uint32_t>(limit - chunk) : 16u;
-    const uint32_t below_lo = (1u << lo) - 1u;
-    const uint32_t nl = eq_mask16(v, 0x0a0a0a0au) & ~below_lo, nul = eq_mask16(v, 0u) & ~below_lo;
-    uint32_t end = hi;
-    bool stop = false;
-    const uint32_t stops = (nl | nul) & ((1u << hi) - 1u);
-    if (stops) {
-      const uint32_t e = __ffs(stops) - 1;
-      end = ((nl >> e) & 1u) ? e + 1 : e;
-      stop = true;
-    }
-    if (first_to == HG_NONE32) {
-#pragma unroll
-      for (int i = 0; i < 16; i++) {
-        if (static_cast<uint32_t>(i) >= lo && static_cast<uint32_t>(i) < end && first_to == HG_NONE32) {
-          const uint32_t c = byte_of(v, i);
-          // inside one line a '\n' is always the last scanned byte
-          const uint32_t cc = c == '\n' ? HG_NC_NLFINAL : (hg_is_word(c) ? HG_NC_WORD : HG_NC_OTHER);
-          const uint32_t *ac = acct + (pc * 5 + cc) * NW, *am = amask + (pc * 4 + cc) * NW, *rc = reach + c * NW;
-          uint32_t hit = 0;
-#pragma unroll
-          for (int w = 0; w < NW; w++) hit |= S[w] & ac[w];
-          if (hit) {
-            first_to = static_cast<uint32_t>(chunk + i - a);
-          } else {
-            uint32_t T[NW];
-#pragma unroll
-            for (int w = 0; w < NW; w++) T[w] = I[w];
-#pragma unroll
-            for (int w = 0; w < NW; w++)
-              for (uint32_t x = S[w]; x; x &= x - 1) {
-                const uint32_t *f = follow + (w * 32 + (__ffs(x) - 1)) * NW;
-#pragma unroll
-                for (int q = 0; q < NW; q++) T[q] |= f[q];
-              }
-#pragma unroll
-            for (int w = 0; w < NW; w++) S[w] = T[w] & rc[w] & am[w];
-            pc = hg_prev_ctx(c);
-          }
-        }
-      }
-    }
-    if (stop || hi < 16) {
-      z = chunk + end;
-      break;
-    }
-  }
-  if (first_to == HG_NONE32) {  // match ending exactly at the end of the scanned bytes
-    const uint32_t *ac = acct + (pc * 5 + HG_NC_END) * NW;
-    uint32_t hit = 0;
-#pragma unroll
-    for (int w = 0; w < NW; w++) hit |= S[w] & ac[w];
-    if (hit) first_to = static_cast<uint32_t>(z - a);
-  }
-  if (first_to != HG_NONE32) emit(line_no, first_to, a, static_cast<uint32_t>(z - a));
-}
-
-// confirm_simple with the pattern's tables staged by the wave in LDS (reach[256], follow[nodes]): no table traffic to HBM / L2.
-template <typename Emit>
-__device__ __forceinline__ void confirm_simple_tab(const uint8_t *text, uint64_t nbytes, const HgTileSum *sums, const HgTileBase *bases, uint64_t bs1, uint64_t pos,
+__device__ __forceinline__ void confirm_simple(const uint8_t *text, uint64_t nbytes, const HgTileSum *sums, const HgTileBase *bases, uint64_t bs1, uint64_t pos,
                                                    uint32_t rank, uint32_t init, uint32_t acc, const lds_u32 *reach, const lds_u32 *follow, Emit &&emit) {
   const uint64_t t = pos >> HG_TILE_SHIFT, tile_start = t << HG_TILE_SHIFT;
   const uint64_t s = rank == 0 ? bases[t].cs : line_start_in_tile(text, tile_start, pos);
@@ -390,12 +246,11 @@ __device__ __forceinline__ void confirm_simple_tab(const uint8_t *text, uint64_t
   if (first_to != HG_NONE32) emit(line_no, first_to, a, static_cast<uint32_t>(z - a));
 }
 
-// confirm_ctx with the pattern's tables staged by the wave in LDS.
-// (original:) Confirm one (candidate, pattern) for a SINGLEMATCH pattern with up to NW <= 2 state words and arbitrary boundary
+// Confirm one (candidate, pattern) for a SINGLEMATCH pattern with up to NW <= 2 state words and arbitrary boundary
 // conditions (^ $ \b ...): same chunked walk as confirm_simple, automaton tables read from HBM/L2 (the handful of
 // 4-byte lookups per text byte depend on the text only, except follow[], so they pipeline).
 template <int NW, typename Emit>
-__device__ __forceinline__ void confirm_ctx_tab(const uint8_t *text, uint64_t nbytes, const HgTileSum *sums, const HgTileBase *bases, uint64_t bs1, uint64_t pos,
+__device__ __forceinline__ void confirm_ctx(const uint8_t *text, uint64_t nbytes, const HgTileSum *sums, const HgTileBase *bases, uint64_t bs1, uint64_t pos,
                                                 uint32_t rank, const lds_u32 *reach, const lds_u32 *follow, const lds_u32 *init, const lds_u32 *amask, const lds_u32 *acct,
                                                 Emit &&emit) {
   const uint64_t t = pos >> HG_TILE_SHIFT, tile_start = t << HG_TILE_SHIFT;

@@ -791,22 +791,20 @@ __global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
   verify_stage_flush(a, s_stage);
 }
 
-// Automaton passes over the deferred lists, one launch per confirm mode present in the database so that lanes of a
-// wave run the same routine and the common modes keep a small register footprint:
+// Confirm passes over the lists of verified occurrences, one routine per confirm mode so that the lanes of a wave do the
+// same work:
 //   MODE 0 literal-only expressions (the verified occurrence is the match: locate the piece, apply the NUL rules),
-//   MODE 1 context-free single-word automaton (follow table in LDS), MODE 2 <= 2 state words with boundary conditions,
+//   MODE 1 context-free single-word automaton, MODE 2 <= 2 state words with boundary conditions (confirm_tables_body),
 //   MODE 3 the scalar reference routine (multi-word state, all-matches mode).
 // vblock / vgrid: this block's index among the blocks working on MODE (several modes can share one launch).
-template <int MODE>
+template <int MODE>  // 0: literal-only, 3: generic
 __device__ __forceinline__ void confirm_body(const HgConfirmArgs &a, uint32_t vblock, uint32_t vgrid) {
   __shared__ uint32_t s_n, s_base;
-  __shared__ uint32_t s_follow[MODE == 1 ? 32 * HG_CONFIRM_THREADS : 1];
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
   const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
   const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n};
-  uint32_t *follow_lds = MODE == 1 ? s_follow + (threadIdx.x >> 6) * (32 * 64) + (threadIdx.x & 63u) : s_follow;
-  // block b walks shard b % HG_DEFER_SHARDS with the blocks that share it
+  // block b walks list b % HG_DEFER_SHARDS with the blocks that share it
   const uint32_t shard = vblock % HG_DEFER_SHARDS, peer = vblock / HG_DEFER_SHARDS, peers = (vgrid + HG_DEFER_SHARDS - 1 - shard) / HG_DEFER_SHARDS;
   const HgDeferred *dlist = a.deferred + (static_cast<uint64_t>(a.list_of_mode[MODE]) * HG_DEFER_SHARDS + shard) * a.defer_shard_cap;
   uint32_t n = a.defer_count[MODE * HG_DEFER_SHARDS + shard];
@@ -817,19 +815,12 @@ __device__ __forceinline__ void confirm_body(const HgConfirmArgs &a, uint32_t vb
     const HgPattern &p = a.db.patterns[pattern];
     const uint32_t id = p.id;
     auto emit = [&](uint64_t line_no, uint32_t to, uint64_t start, uint32_t len) { sink.push(line_no, id, to, start, len, pattern); };
-    if (MODE == 0) {
-      hgdev::confirm_literal(a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, d.rank, d.pos - (d.pattern >> 24), p.lit_len, emit);
-    } else if (MODE == 1) {
-      hgdev::confirm_simple(a.db, a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, p, d.rank, follow_lds, emit);
-    } else if (MODE == 2) {
-      if (p.nw == 1) hgdev::confirm_ctx<1>(a.db, a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, p, d.rank, emit);
-      else hgdev::confirm_ctx<2>(a.db, a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, p, d.rank, emit);
-    } else {
-      hg_confirm(a.db, a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, pattern, d.rank, emit);
-    }
+    if (MODE == 0) hgdev::confirm_literal(a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, d.rank, d.pos - (d.pattern >> 24), p.lit_len, emit);
+    else hg_confirm(a.db, a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, pattern, d.rank, emit);
   }
   flush_hits(a, &s_n, &s_base);
 }
+
 // Modes 1 and 2 (automata of one or two state words).  Run with the tables in HBM, one such occurrence costs hundreds of
 // scattered 4-byte loads (reach / follow / boundary masks per text byte) and the pass is bound by memory requests.  Here
 // the lists are keyed by pattern (the verify pass files an occurrence under pattern % HG_DEFER_SHARDS), each block takes an
@@ -897,12 +888,12 @@ __device__ __forceinline__ void confirm_tables_body(const HgConfirmArgs &a, uint
         const uint32_t id = p.id;
         auto emit = [&](uint64_t line_no, uint32_t to, uint64_t start_, uint32_t len) { sink.push(line_no, id, to, start_, len, pat); };
         if (MODE == 1) {
-          hgdev::confirm_simple_tab(a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, d.rank, p.init_word, p.acc_all, tab + CT_REACH, tab + CT_FOLLOW, emit);
+          hgdev::confirm_simple(a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, d.rank, p.init_word, p.acc_all, tab + CT_REACH, tab + CT_FOLLOW, emit);
         } else if (nw == 1) {
-          hgdev::confirm_ctx_tab<1>(a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, d.rank, tab + CT_REACH, tab + CT_FOLLOW, tab + CT_INIT, tab + CT_AMASK, tab + CT_ACC,
+          hgdev::confirm_ctx<1>(a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, d.rank, tab + CT_REACH, tab + CT_FOLLOW, tab + CT_INIT, tab + CT_AMASK, tab + CT_ACC,
                                     emit);
         } else {
-          hgdev::confirm_ctx_tab<2>(a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, d.rank, tab + CT_REACH, tab + CT_FOLLOW, tab + CT_INIT, tab + CT_AMASK, tab + CT_ACC,
+          hgdev::confirm_ctx<2>(a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, d.rank, tab + CT_REACH, tab + CT_FOLLOW, tab + CT_INIT, tab + CT_AMASK, tab + CT_ACC,
                                     emit);
         }
       }
