@@ -517,3 +517,35 @@ def test_random_literal_anchored_patterns_match_oracle(torch_cuda, seed):
     assert stats.n_lines == nlines
     assert got == want, (pats, flags, ids)
     assert len(want) > 500
+
+
+@pytest.mark.parametrize("mib, chunk_tiles, seed", [(97, 1024, 1), (333, 4096, 2), (700, 8192, 3), (1311, 16384, 4)])
+def test_chunked_pipeline_equals_single_pass(torch_cuda, monkeypatch, mib, chunk_tiles, seed):
+    """The chunked two-stream pipeline (early sort of the first chunks + merge, carried line numbers, double-buffered
+    candidates) and the single pass must deliver identical records, for chunk counts from 3 to 6 and ragged sizes."""
+    from hypergrep_amd import benchspec, device
+
+    torch = torch_cuda
+    patterns, needles, hpm = benchspec.c3_spec()
+    ids = list(range(len(patterns)))
+    nbytes = (mib << 20) + 12345 * seed
+    text = torch.empty(nbytes + 64, dtype=torch.uint8, device="cuda:0")
+    device.synth_device(text.data_ptr(), nbytes, 5000 + seed, needles, hpm * 2)
+    torch.cuda.synchronize()
+    sc = device.Scanner(device.Database(patterns, ids=ids), 0)
+
+    def run():
+        st = sc.scan(text.data_ptr(), nbytes, line_base=77)
+        buf = torch.empty((st.n_hits, 2), dtype=torch.int64, device="cuda:0")
+        sc.copy_hits_to(buf.data_ptr(), st.n_hits)
+        torch.cuda.synchronize()
+        return st, buf
+
+    monkeypatch.setenv("HG_CHUNK_TILES", str(1 << 30))
+    one, a = run()
+    assert one.stream_launches == 1
+    monkeypatch.setenv("HG_CHUNK_TILES", str(chunk_tiles))
+    many, b = run()
+    assert many.stream_launches >= 3
+    assert (many.n_hits, many.n_lines) == (one.n_hits, one.n_lines) and one.n_hits > 10000
+    assert bool((a == b).all())
