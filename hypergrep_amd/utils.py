@@ -1,6 +1,6 @@
 """hypergrep-compatible Python API on top of the MI355X scan engine.
 
-Mirrors the reference's public surface (hypergrep/utils.py) name for name, default for default:
+The public surface of the reference's hypergrep/utils.py, name for name and default for default:
 
     Result / CALLBACK_TYPE          utils.py:25-51      batched-match C struct and callback type
     check_compatibility()           utils.py:97-122     compile-only probe, 0 or 4
@@ -23,168 +23,100 @@ import ctypes
 import os
 import re
 import threading
-from typing import Callable
+from typing import Callable, Sequence
 
-# Flags pulled from hs_compile.h (reference utils.py:10-13).
-HS_FLAG_CASELESS = 1
-HS_FLAG_DOTALL = 2
-HS_FLAG_MULTILINE = 4
-HS_FLAG_SINGLEMATCH = 8
+# Hyperscan's compile flags, the values the reference passes through (utils.py:10-13).
+HS_FLAG_CASELESS, HS_FLAG_DOTALL, HS_FLAG_MULTILINE, HS_FLAG_SINGLEMATCH = 1, 2, 4, 8
+_GREP_FLAGS = HS_FLAG_DOTALL | HS_FLAG_MULTILINE | HS_FLAG_SINGLEMATCH  # what grep() and the default of scan() use
 
-# Reference utils.py:16.
-RC_INVALID_FILE = 101
-
-__libhs__ = None
-__libhs_path__ = ""
-__libhyperscanner__ = None
-__libzstd__ = None
-__libzstd_path__ = ""
+RC_INVALID_FILE = 101  # grep(): the path is missing or a directory (utils.py:16)
+_RC_INTERRUPTED = 130
+_JOIN_TIMEOUT_S = 3600
 
 
 class Result(ctypes.Structure):
-    """One match: pattern id, 0-based line index, line bytes (reference utils.py:25-40; hyperscanner.c:42-46)."""
+    """One match as the shim lays it out (hyperscanner.c:42-46): report id, 0-based line index, the line's bytes."""
 
-    _fields_ = [
-        ("id", ctypes.c_uint),
-        ("line_number", ctypes.c_ulonglong),
-        ("line", ctypes.c_char_p),
-    ]
+    _fields_ = [("id", ctypes.c_uint), ("line_number", ctypes.c_ulonglong), ("line", ctypes.c_char_p)]
 
 
-CALLBACK_TYPE = ctypes.CFUNCTYPE(
-    None,
-    ctypes.POINTER(Result),
-    ctypes.c_int,
-    use_errno=False,
-    use_last_error=False,
-)
+# void on_event(Result *batch, int count)  (hyperscanner.c:54)
+CALLBACK_TYPE = ctypes.CFUNCTYPE(None, ctypes.POINTER(Result), ctypes.c_int, use_errno=False, use_last_error=False)
 
 
-def _default_library() -> str:
-    return os.path.join(os.path.abspath(os.path.dirname(__file__)), "lib", "libhyperscanner.so")
+class _Libraries:
+    """Paths chosen through configure_libraries() and the handles once loaded (loading is lazy: a forked worker must
+    initialise the GPU runtime itself)."""
+
+    engine_path = ""
+    zstd_path = ""
+    engine = None
+    zstd = None
+
+    @staticmethod
+    def default_engine() -> str:
+        return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libhyperscanner.so")
 
 
 def _get_hyperscanner_lib() -> ctypes.CDLL:
-    """Lazily load the native library (lazily so that forked worker processes initialise HIP themselves)."""
-    global __libhyperscanner__, __libzstd__, __libhs__  # pylint: disable=global-statement
-    if __libzstd__ is None and __libzstd_path__:
-        __libzstd__ = ctypes.CDLL(__libzstd_path__, mode=ctypes.RTLD_GLOBAL)
-    if __libhyperscanner__ is None:
-        path = __libhs_path__ or _default_library()
+    if _Libraries.zstd is None and _Libraries.zstd_path:
+        _Libraries.zstd = ctypes.CDLL(_Libraries.zstd_path, mode=ctypes.RTLD_GLOBAL)
+    if _Libraries.engine is None:
+        path = _Libraries.engine_path or _Libraries.default_engine()
         if not os.path.exists(path):
             raise OSError(
                 f"{path}: native library not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(needs hipcc); hypergrep_amd has no pure-Python or CPU fallback."
             )
-        __libhyperscanner__ = ctypes.cdll.LoadLibrary(path)
-        __libhs__ = __libhyperscanner__
-    return __libhyperscanner__
-
-
-def check_compatibility(patterns: list, flags: list[int] = ()) -> int:
-    """Test pattern compilation without scanning a file; 0 if every pattern compiles, else 4."""
-    pattern_array, flags_array, ids_array = prepare_patterns(patterns, flags=flags)
-    lib = _get_hyperscanner_lib()
-    return lib.check_patterns(pattern_array, flags_array, ids_array, len(pattern_array))
+        _Libraries.engine = ctypes.cdll.LoadLibrary(path)
+    return _Libraries.engine
 
 
 def configure_libraries(libhs: str | None = None, libzstd: str | None = None) -> None:
-    """Set the paths to library files; must run before first use (reference utils.py:125-144).
+    """Choose other library files; only possible before the first scan / check loads them.
 
-    libhs: path of the engine library (this package's libhyperscanner.so by default).
-    libzstd: alternative libzstd to preload for .zst input.
+    libhs: the engine library (default: this package's libhyperscanner.so).  libzstd: a libzstd to preload for .zst input.
     """
-    if libhs:
-        if __libhs__:
-            raise ValueError("libhs already loaded, configuration overrides must be called before library usage")
-        global __libhs_path__  # pylint: disable=global-statement
-        __libhs_path__ = libhs
-    if libzstd:
-        if __libzstd__:
-            raise ValueError("libzstd already loaded, configuration overrides must be called before library usage")
-        global __libzstd_path__  # pylint: disable=global-statement
-        __libzstd_path__ = libzstd
+    in_use = _Libraries.engine is not None  # the engine opens its libzstd itself, so both are fixed once it is loaded
+    for name, wanted, slot in (("libhs", libhs, "engine_path"), ("libzstd", libzstd, "zstd_path")):
+        if not wanted:
+            continue
+        if in_use:
+            raise ValueError(f"{name} already loaded, configuration overrides must be called before library usage")
+        setattr(_Libraries, slot, wanted)
 
 
-def grep(  # pylint: disable=too-many-arguments
-    file: str,
-    patterns: list[str],
-    ignore_case: bool = False,
-    count_only: bool = False,
-    only_matching: bool = False,
-    no_messages: bool = False,
-    errors: str = "ignore",
-    max_match_count: int = 0,
-) -> tuple[int | list[tuple[int, str]], int]:
-    """grep-like helper returning (count | [(1-based line number, line)], return code); reference utils.py:147-231."""
-    return_code = 0
-    compiled_patterns = [re.compile(pattern) for pattern in patterns]
-    results = [] if not count_only else 0
-
-    if not os.path.exists(file):
-        return_code = RC_INVALID_FILE
-        if not no_messages:
-            raise FileNotFoundError("No such file or directory")
-    if os.path.isdir(file):
-        return_code = RC_INVALID_FILE
-        if not no_messages:
-            raise ValueError("is a directory")
-
-    if not return_code:
-
-        def _c_callback(matches: list, count: int) -> None:
-            nonlocal results
-            if count_only:
-                results += count
-            elif only_matching:
-                for index in range(count):
-                    match = matches[index]
-                    line = match.line.decode(errors=errors)
-                    for partial in compiled_patterns[match.id].finditer(line):
-                        results.append((match.line_number + 1, f"{partial.group()}\n"))
-            else:
-                for index in range(count):
-                    match = matches[index]
-                    results.append((match.line_number + 1, match.line.decode(errors=errors)))
-
-        flags = HS_FLAG_DOTALL | HS_FLAG_MULTILINE | HS_FLAG_SINGLEMATCH
-        if ignore_case:
-            flags |= HS_FLAG_CASELESS
-        return_code = scan(file, patterns, _c_callback, flags=[flags for _ in patterns], max_match_count=max_match_count)
-
-    return results, return_code
-
-
-def prepare_patterns(
-    patterns: list[str],
-    flags: list[int] = (),
-    ids: list[int] = (),
-) -> tuple[ctypes.Array, ctypes.Array, ctypes.Array]:
-    """Python patterns / flags / ids -> C arrays (reference utils.py:234-289; same defaults and errors)."""
-    if not flags:
-        flags = [HS_FLAG_DOTALL | HS_FLAG_MULTILINE | HS_FLAG_SINGLEMATCH for _ in patterns]
-    if len(flags) != len(patterns):
+def _one_per_pattern(kind: str, values: Sequence[int], default: int, count: int) -> list[int]:
+    chosen = list(values) if values else [default] * count
+    if len(chosen) != count:
         raise ValueError(
-            f"Found {len(flags)} flags, expecting {len(patterns)}. Hyperscan flags must be provided for each regex to compile the database."
+            f"Found {len(chosen)} {kind}, expecting {count}. Hyperscan {kind} must be provided for each regex to compile the database."
         )
-    if not ids:
-        ids = [0 for _ in patterns]
-    if len(ids) != len(patterns):
-        raise ValueError(
-            f"Found {len(ids)} ids, expecting {len(patterns)}. Hyperscan ids must be provided for each regex to compile the database."
-        )
-    encoded_patterns = []
+    return chosen
+
+
+def prepare_patterns(patterns: list[str], flags: list[int] = (), ids: list[int] = ()) -> tuple[ctypes.Array, ctypes.Array, ctypes.Array]:
+    """Patterns, per-pattern flags (default DOTALL | MULTILINE | SINGLEMATCH) and report ids (default all 0) as C arrays.
+
+    ValueError for an empty pattern or when flags / ids are given but not one per pattern.
+    """
+    count = len(patterns)
+    flag_values = _one_per_pattern("flags", flags, _GREP_FLAGS, count)
+    id_values = _one_per_pattern("ids", ids, 0, count)
     for pattern in patterns:
         if not pattern:
             raise ValueError(f'Invalid pattern "{pattern}" found. Please provide a valid regex for Intel Hyperscan.')
-        encoded_patterns.append(pattern.encode())
-    pattern_array = (ctypes.c_char_p * (len(encoded_patterns)))()
-    pattern_array[:] = encoded_patterns
-    flags_array = (ctypes.c_uint * (len(flags)))()
-    flags_array[:] = [ctypes.c_uint(flag) for flag in flags]
-    ids_array = (ctypes.c_uint * (len(ids)))()
-    ids_array[:] = [ctypes.c_uint(id_num) for id_num in ids]
-    return pattern_array, flags_array, ids_array
+    return (
+        (ctypes.c_char_p * count)(*[pattern.encode() for pattern in patterns]),
+        (ctypes.c_uint * count)(*flag_values),
+        (ctypes.c_uint * count)(*id_values),
+    )
+
+
+def check_compatibility(patterns: list, flags: list[int] = ()) -> int:
+    """Compile the patterns without scanning anything: 0 if the engine accepts them all, else 4."""
+    c_patterns, c_flags, c_ids = prepare_patterns(patterns, flags=flags)
+    return _get_hyperscanner_lib().check_patterns(c_patterns, c_flags, c_ids, len(c_patterns))
 
 
 def scan(  # pylint: disable=too-many-arguments
@@ -197,30 +129,83 @@ def scan(  # pylint: disable=too-many-arguments
     buffer_count: int = 16,
     max_match_count: int = 0,
 ) -> int:
-    """Scan a plain / gzip / zstd text file; `callback(matches, count)` receives batches (reference utils.py:292-358)."""
-    pattern_array, flags_array, ids_array = prepare_patterns(patterns, flags=flags, ids=ids)
-    callback = CALLBACK_TYPE(callback)
-    lib = _get_hyperscanner_lib()
-    ret_code = 0
+    """Scan a plain / gzip / zstd text file; `callback(matches, count)` receives the hits in batches of `buffer_count`.
 
-    def _wrapper() -> None:
-        nonlocal ret_code
-        ret_code = lib.hyperscan(
-            path.encode(),
-            pattern_array,
-            flags_array,
-            ids_array,
-            len(pattern_array),
-            callback,
-            buffer_size,
-            buffer_count,
-            ctypes.c_ulonglong(max_match_count),
-        )
+    The native call runs on a daemon thread so that Ctrl-C reaches Python (return code 130); otherwise the shim's
+    return code (0 = fine, 1-7 as in hyperscanner.c:25-33) comes back.
+    """
+    c_patterns, c_flags, c_ids = prepare_patterns(patterns, flags=flags, ids=ids)
+    c_callback = CALLBACK_TYPE(callback)  # referenced until the call is over
+    engine = _get_hyperscanner_lib()
+    outcome = [0]
 
-    thread = threading.Thread(target=_wrapper, daemon=True)
-    thread.start()
+    def native_call() -> None:
+        outcome[0] = engine.hyperscan(path.encode(), c_patterns, c_flags, c_ids, len(c_patterns), c_callback, buffer_size, buffer_count,
+                                      ctypes.c_ulonglong(max_match_count))
+
+    worker = threading.Thread(target=native_call, daemon=True)
+    worker.start()
     try:
-        thread.join(timeout=3600)
+        worker.join(timeout=_JOIN_TIMEOUT_S)
     except KeyboardInterrupt:
-        ret_code = 130
-    return ret_code
+        return _RC_INTERRUPTED
+    return outcome[0]
+
+
+class _GrepSink:
+    """on_match for grep(): counts, keeps whole lines, or keeps the matched parts (`re.finditer` of the pattern whose
+    id the hit carries — with grep()'s all-zero ids that is the first pattern, as in the reference)."""
+
+    def __init__(self, patterns: list[str], count_only: bool, only_matching: bool, errors: str):
+        self.count = 0
+        self.rows: list[tuple[int, str]] = []
+        self.count_only = count_only
+        self.errors = errors
+        self.finders = [re.compile(pattern) for pattern in patterns] if only_matching else None
+
+    def __call__(self, matches, count: int) -> None:
+        if self.count_only:
+            self.count += count
+            return
+        for hit in (matches[i] for i in range(count)):
+            text = hit.line.decode(errors=self.errors)
+            if self.finders is None:
+                self.rows.append((hit.line_number + 1, text))
+            else:
+                self.rows.extend((hit.line_number + 1, f"{part.group()}\n") for part in self.finders[hit.id].finditer(text))
+
+    def result(self):
+        return self.count if self.count_only else self.rows
+
+
+def grep(  # pylint: disable=too-many-arguments
+    file: str,
+    patterns: list[str],
+    ignore_case: bool = False,
+    count_only: bool = False,
+    only_matching: bool = False,
+    no_messages: bool = False,
+    errors: str = "ignore",
+    max_match_count: int = 0,
+) -> tuple[int | list[tuple[int, str]], int]:
+    """grep for Python: (number of matching lines | [(1-based line number, line)], return code).
+
+    A missing path raises FileNotFoundError and a directory ValueError — or, with `no_messages`, comes back as
+    (nothing found, 101).  Invalid regexes raise `re.error` before anything is scanned.
+    """
+    sink = _GrepSink(patterns, count_only, only_matching, errors)
+    if not only_matching:
+        for pattern in patterns:  # the reference compiles them for -o in every mode: same early failure for bad syntax
+            re.compile(pattern)
+    problem = None
+    if not os.path.exists(file):
+        problem = FileNotFoundError("No such file or directory")
+    elif os.path.isdir(file):
+        problem = ValueError("is a directory")
+    if problem is not None:
+        if not no_messages:
+            raise problem
+        return sink.result(), RC_INVALID_FILE
+    flags = _GREP_FLAGS | (HS_FLAG_CASELESS if ignore_case else 0)
+    return_code = scan(file, patterns, sink, flags=[flags] * len(patterns), max_match_count=max_match_count)
+    return sink.result(), return_code
