@@ -588,6 +588,44 @@ void check_embedded_anchors(const Node &n, bool before, bool after) {
   }
 }
 
+// Longest string the expression can match; -1 = unbounded (or absurdly long).
+long max_match_len(const Node &n) {
+  const long kCap = 1 << 20;
+  switch (n.kind) {
+    case Node::Empty:
+    case Node::Assert: return 0;
+    case Node::Class: return 1;
+    case Node::Cat: {
+      long t = 0;
+      for (auto &k : n.kids) {
+        long v = max_match_len(*k);
+        if (v < 0) return -1;
+        t += v;
+        if (t > kCap) return -1;
+      }
+      return t;
+    }
+    case Node::Alt: {
+      long t = 0;
+      for (auto &k : n.kids) {
+        long v = max_match_len(*k);
+        if (v < 0) return -1;
+        t = std::max(t, v);
+      }
+      return t;
+    }
+    case Node::Rep: {
+      long v = n.kids.empty() ? 0 : max_match_len(*n.kids[0]);
+      if (v < 0) return -1;
+      if (v == 0) return 0;
+      if (n.max < 0) return -1;
+      long t = v * n.max;
+      return t > kCap ? -1 : t;
+    }
+  }
+  return -1;
+}
+
 bool has_assert(const Node &n) {
   if (n.kind == Node::Assert) return true;
   for (auto &k : n.kids) if (has_assert(*k)) return true;
@@ -1287,7 +1325,10 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
         for (size_t j = 0; j < lb.size(); j++)
           if (lb[j] == 0 || (lb[j] == '\n' && j + 1 < lb.size())) clean = false;
         p.literal_only = clean ? 1 : 0;
-        p.lit_len = clean ? static_cast<uint32_t>(lb.size()) : 0;
+      }
+      {
+        const long ml = max_match_len(*root);
+        p.max_len = ml > 0 ? static_cast<uint32_t>(ml) : 0;
       }
       if (fast) db->n_confirm_mode[hg_confirm_mode(p)]++;
       if (fast) {
@@ -1308,6 +1349,16 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
     if (err) *err = "out of memory";
     if (bad_index) *bad_index = static_cast<int>(cur);
     return -2;
+  }
+
+  // always-on patterns of bounded length and at most two state words go first: the segment-parallel kernel takes those
+  {
+    auto fast = [&](uint32_t pi) {
+      const HgPattern &p = db->patterns[pi];
+      return p.max_len >= 1 && p.max_len <= HG_ALWAYS_ON_FAST_MAX_LEN && p.nw <= 2;
+    };
+    std::stable_partition(db->slow.begin(), db->slow.end(), fast);
+    db->nslow_fast = static_cast<uint32_t>(std::count_if(db->slow.begin(), db->slow.end(), fast));
   }
 
   // factors (needs the final fold mask); windows and filter tables are built from them

@@ -23,7 +23,8 @@ struct HgDb {
   uint32_t filter_wide = 0;          // 1: two 16-bit fingerprints per slot, no neighbour conditions (large pattern sets)
   uint32_t weights_a = HG_SLOT_WEIGHT_CHOICES[0][0], weights_b = HG_SLOT_WEIGHT_CHOICES[0][1];
   std::vector<HgSlotInfo> ext;       // per filter slot: the window values in it and their neighbour-dword conditions (second-level check)
-  std::vector<uint32_t> slow;        // indices of tier-1 (always-on) patterns
+  std::vector<uint32_t> slow;        // indices of tier-1 (always-on) patterns, the nslow_fast bounded ones with <= 2 state words first
+  uint32_t nslow_fast = 0;
   uint32_t fold_mask = 0;            // 0x20202020 when any tier-0 pattern is case-insensitive
   uint32_t max_nw = 1;
   uint32_t max_id = 0;               // largest report id (sizes the sort key)

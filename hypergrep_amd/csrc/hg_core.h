@@ -53,7 +53,8 @@ struct HgDbView {
   const uint32_t *bucket_off2;
   const HgWindow *windows2;
   const uint32_t *slow;
-  uint32_t npatterns, nslow, fold_mask, pad;
+  uint32_t npatterns, nslow, fold_mask;
+  uint32_t nslow_fast;  // the first nslow_fast entries of `slow` are bounded, <= 2 state words: hg_always_on_fast_kernel takes them
 };
 
 // 0x80 in every byte of x that is zero, exact (no borrow between bytes).
@@ -269,7 +270,7 @@ HG_HD void hg_confirm(const HgDbView &db, const uint8_t *text, uint64_t nbytes, 
 // newlines before it in its tile) with every tier-1 pattern.  emit(pattern, line_no, to, a, len).
 template <typename Emit>
 HG_HD void hg_scan_line_always_on(const HgDbView &db, const uint8_t *text, uint64_t nbytes, const HgTileSum *sums,
-                                  const HgTileBase *bases, uint64_t bs1, uint64_t s, uint32_t rank, Emit &&emit) {
+                                  const HgTileBase *bases, uint64_t bs1, uint64_t s, uint32_t rank, uint32_t first, uint32_t last, Emit &&emit) {
   uint64_t t = s >> HG_TILE_SHIFT, tile_start = t << HG_TILE_SHIFT;
   uint64_t line_no = hg_line_index(text, sums[t], bases[t], tile_start, rank, s, bs1, bs1 < HG_TILE_BYTES);
   uint64_t ps = s;
@@ -278,7 +279,7 @@ HG_HD void hg_scan_line_always_on(const HgDbView &db, const uint8_t *text, uint6
     uint64_t a, z;
     hg_trim_piece(text, ps, limit, a, z);
     if (z > a) {
-      for (uint32_t j = 0; j < db.nslow; j++) {
+      for (uint32_t j = first; j < last; j++) {  // entries [first, last) of the always-on list
         uint32_t pi = db.slow[j];
         hg_nfa_scan(db.pool, db.patterns[pi], text + a, z - a,
                     [&](uint32_t to) { emit(pi, line_no, to, a, static_cast<uint32_t>(z - a)); });

@@ -26,6 +26,7 @@ constexpr uint32_t HG_TT_ALL = (1u << 20) - 1;
 constexpr uint32_t HG_MAX_NODES = 1024;  // per pattern (32 state words)
 constexpr uint32_t HG_MAX_W = HG_MAX_NODES / 32;
 constexpr uint32_t HG_MAX_PATTERNS = 1u << 24;  // pattern index and window offset share one word in the verified-occurrence records
+constexpr uint32_t HG_ALWAYS_ON_FAST_MAX_LEN = 64;  // longest match of an always-on pattern the segment-parallel kernel takes
 constexpr uint32_t HG_FACTOR_MAX = 32;   // bytes of a required literal kept for the in-stream verify
 // A window = the low HG_WINDOW_BYTES bytes of a dword-aligned text dword.  4 and 3 are supported; measured on the
 // round-1 workload a 3-byte window admits 6-byte literals to the fast tier but is hit 1.5x more often by filler text.
@@ -74,7 +75,7 @@ struct HgPattern {
   uint32_t acc_all;     // accepting nodes when `simple`
   uint32_t init_word;   // init[0] when `simple`
   uint32_t literal_only;  // the whole expression is one literal (its factor): a verified occurrence IS the match
-  uint32_t lit_len;       // length of that literal when literal_only
+  uint32_t max_len;       // longest possible match in bytes, 0 = unbounded (literal_only: the literal's length)
 };
 static_assert(sizeof(HgPattern) == 64, "HgPattern layout");
 

@@ -22,7 +22,8 @@ __global__ void hg_tile_inner_kernel(const uint8_t *text, HgTileSum *sums, uint6
 __global__ void hg_verify_kernel(HgConfirmArgs a);
 __global__ void hg_confirm_fast_kernel(HgConfirmArgs a, uint32_t blocks_per_mode);
 __global__ void hg_confirm_generic_kernel(HgConfirmArgs a);
-__global__ void hg_always_on_kernel(HgConfirmArgs a);
+__global__ void hg_always_on_kernel(HgConfirmArgs a, uint32_t first, uint32_t last);
+__global__ void hg_always_on_fast_kernel(HgConfirmArgs a);
 __global__ void hg_block_mark_kernel(HgConfirmArgs a, uint32_t *pattern_flags);
 __global__ void hg_block_scan_kernel(HgConfirmArgs a, const uint32_t *pattern_flags);
 __global__ void hg_key_kernel(const HgHit *hits, const HgHitAux *aux, const HgPattern *patterns, uint32_t n, uint64_t *key, uint32_t *idx);
@@ -105,6 +106,7 @@ int HgScanner::create(const HgDb *db, int device, HgScanner **out, std::string *
   s->view_.slow = static_cast<const uint32_t *>(s->d_slow_);
   s->view_.npatterns = static_cast<uint32_t>(db->patterns.size());
   s->view_.nslow = static_cast<uint32_t>(db->slow.size());
+  s->view_.nslow_fast = db->nslow_fast;
   s->view_.fold_mask = db->fold_mask;
   HG_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_counters_), HG_CNT_WORDS * 4), "alloc counters");
   HG_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_selected_), 16), "alloc counters");
@@ -371,7 +373,9 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
         if (!db_->slow.empty()) {
           always_blocks = static_cast<uint32_t>(std::min<uint64_t>((span + 3) / 4, static_cast<uint64_t>(num_cus_) * 8));
           ca.hit_seg_cap = hit_cap_ / always_blocks;
-          hipLaunchKernelGGL(hg_always_on_kernel, dim3(always_blocks), dim3(256), 0, side, ca);
+          const uint32_t nfast = db_->nslow_fast, nall = static_cast<uint32_t>(db_->slow.size());
+          if (nfast) hipLaunchKernelGGL(hg_always_on_fast_kernel, dim3(always_blocks), dim3(256), 0, side, ca);
+          if (nall > nfast) hipLaunchKernelGGL(hg_always_on_kernel, dim3(always_blocks), dim3(256), 0, side, ca, nfast, nall);
           HG_TRY(hipGetLastError(), "hg_always_on_kernel launch");
         }
       }

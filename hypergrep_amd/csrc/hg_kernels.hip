@@ -815,7 +815,7 @@ __device__ __forceinline__ void confirm_body(const HgConfirmArgs &a, uint32_t vb
     const HgPattern &p = a.db.patterns[pattern];
     const uint32_t id = p.id;
     auto emit = [&](uint64_t line_no, uint32_t to, uint64_t start, uint32_t len) { sink.push(line_no, id, to, start, len, pattern); };
-    if (MODE == 0) hgdev::confirm_literal(a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, d.rank, d.pos - (d.pattern >> 24), p.lit_len, emit);
+    if (MODE == 0) hgdev::confirm_literal(a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, d.rank, d.pos - (d.pattern >> 24), p.max_len, emit);
     else hg_confirm(a.db, a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, pattern, d.rank, emit);
   }
   flush_hits(a, &s_n, &s_base);
@@ -827,6 +827,26 @@ __device__ __forceinline__ void confirm_body(const HgConfirmArgs &a, uint32_t vb
 // equal slice of the concatenated lists, and a wave stages the tables of ONE pattern at a time in LDS (<= 3 KiB) and runs
 // the lanes whose occurrence belongs to it: a slice holds a handful of patterns, and the only HBM traffic left is the text.
 constexpr uint32_t CT_REACH = 0, CT_FOLLOW = 512, CT_INIT = 640, CT_AMASK = 644, CT_ACC = 676, CT_WORDS = 768;  // dword offsets in a wave's table area
+// A wave copies the automaton tables of ONE pattern into its LDS area (<= 3 KiB): reach[256][nw] as 16-byte pieces, the
+// small tables a dword per lane.
+template <bool WITH_CONTEXT>
+__device__ __forceinline__ void stage_tables(hgdev::lds_u32 *tab, const uint32_t *pool, const HgPattern &p, uint32_t nw, uint32_t lane) {
+  const uint4 *rsrc = reinterpret_cast<const uint4 *>(pool + p.reach_off);
+  const uint4 r0 = rsrc[lane];
+  tab[CT_REACH + 4 * lane + 0] = r0.x; tab[CT_REACH + 4 * lane + 1] = r0.y; tab[CT_REACH + 4 * lane + 2] = r0.z; tab[CT_REACH + 4 * lane + 3] = r0.w;
+  if (nw == 2) {
+    const uint4 r1 = rsrc[64 + lane];
+    tab[CT_REACH + 256 + 4 * lane + 0] = r1.x; tab[CT_REACH + 256 + 4 * lane + 1] = r1.y; tab[CT_REACH + 256 + 4 * lane + 2] = r1.z; tab[CT_REACH + 256 + 4 * lane + 3] = r1.w;
+  }
+  const uint32_t nfollow = p.nnodes * nw;  // <= 128
+  for (uint32_t i = lane; i < nfollow; i += 64) tab[CT_FOLLOW + i] = pool[p.follow_off + i];
+  if (WITH_CONTEXT) {
+    if (lane < nw) tab[CT_INIT + lane] = pool[p.init_off + lane];
+    if (lane < 16 * nw) tab[CT_AMASK + lane] = pool[p.amask_off + lane];
+    if (lane < 20 * nw) tab[CT_ACC + lane] = pool[p.acc_off + lane];
+  }
+}
+
 template <int MODE>
 __device__ __forceinline__ void confirm_tables_body(const HgConfirmArgs &a, uint32_t vblock, uint32_t vgrid) {
   __shared__ uint32_t s_n, s_base;
@@ -866,22 +886,7 @@ __device__ __forceinline__ void confirm_tables_body(const HgConfirmArgs &a, uint
       todo &= ~__builtin_amdgcn_ballot_w64(mine);
       const HgPattern &p = a.db.patterns[pat];  // wave-uniform: scalar loads
       const uint32_t nw = MODE == 1 ? 1u : p.nw;
-      {  // stage the tables: reach[256][nw] as 16-byte pieces, the small ones a dword per lane
-        const uint4 *rsrc = reinterpret_cast<const uint4 *>(a.db.pool + p.reach_off);
-        uint4 r0 = rsrc[lane];
-        tab[CT_REACH + 4 * lane + 0] = r0.x; tab[CT_REACH + 4 * lane + 1] = r0.y; tab[CT_REACH + 4 * lane + 2] = r0.z; tab[CT_REACH + 4 * lane + 3] = r0.w;
-        if (nw == 2) {
-          uint4 r1 = rsrc[64 + lane];
-          tab[CT_REACH + 256 + 4 * lane + 0] = r1.x; tab[CT_REACH + 256 + 4 * lane + 1] = r1.y; tab[CT_REACH + 256 + 4 * lane + 2] = r1.z; tab[CT_REACH + 256 + 4 * lane + 3] = r1.w;
-        }
-        const uint32_t nfollow = p.nnodes * nw;  // <= 128
-        for (uint32_t i = lane; i < nfollow; i += 64) tab[CT_FOLLOW + i] = a.db.pool[p.follow_off + i];
-        if (MODE == 2) {
-          if (lane < nw) tab[CT_INIT + lane] = a.db.pool[p.init_off + lane];
-          if (lane < 16 * nw) tab[CT_AMASK + lane] = a.db.pool[p.amask_off + lane];
-          if (lane < 20 * nw) tab[CT_ACC + lane] = a.db.pool[p.acc_off + lane];
-        }
-      }
+      stage_tables<MODE == 2>(tab, a.db.pool, p, nw, lane);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       if (mine) {
@@ -918,7 +923,8 @@ __global__ __launch_bounds__(HG_CONFIRM_THREADS) void hg_confirm_fast_kernel(HgC
 __global__ __launch_bounds__(256) void hg_confirm_generic_kernel(HgConfirmArgs a) { confirm_body<3>(a, blockIdx.x, gridDim.x); }
 
 // Always-on tier: one wave per tile, each lane owns 256 bytes and handles the lines that START there.
-__global__ __launch_bounds__(256) void hg_always_on_kernel(HgConfirmArgs a) {
+// Scalar always-on pass over the entries [first, last) of the always-on list.
+__global__ __launch_bounds__(256) void hg_always_on_kernel(HgConfirmArgs a, uint32_t first, uint32_t last) {
   __shared__ uint32_t s_n, s_base;
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
@@ -936,11 +942,168 @@ __global__ __launch_bounds__(256) void hg_always_on_kernel(HgConfirmArgs a) {
     for (uint64_t s = lo; s < hi; s++) {
       const bool starts = s == 0 || a.text[s - 1] == '\n';
       if (starts)
-        hg_scan_line_always_on(a.db, a.text, a.nbytes, a.sums, a.bases, a.bs1, s, rank,
+        hg_scan_line_always_on(a.db, a.text, a.nbytes, a.sums, a.bases, a.bs1, s, rank, first, last,
                                [&](uint32_t pi, uint64_t line_no, uint32_t to, uint64_t start, uint32_t len) {
                                  sink.push(line_no, a.db.patterns[pi].id, to, start, len, pi);
                                });
       rank += a.text[s] == '\n';
+    }
+  }
+  flush_hits(a, &s_n, &s_base);
+}
+
+// Always-on patterns of bounded length (and <= 2 state words), segment-parallel.  A match of such a pattern that ends in a
+// lane's 256-byte segment starts at most max_len - 1 bytes before it, so every lane runs the automaton over its own
+// segment plus that much lead-in, independently of the others; '\n' and NUL reset the automaton (a line is scanned on its
+// own, a NUL ends the scanned bytes), and what the reset cannot know — whether an earlier NUL already ended the line — the
+// line geometry decides when a match is reported (LineHead.blocked).  A SINGLEMATCH pattern can report once per lane and
+// line; the ordering pass keeps the smallest end offset.  Tiles in which a forced break of an over-long line falls
+// (carry-in line start more than buffer_size - 1 bytes before the tile end) go through the scalar routine instead.
+// Tables: one pattern at a time, staged per wave in LDS like the automaton confirm routines.
+template <int NW, bool SIMPLE>
+__device__ __forceinline__ void always_on_segment(const HgConfirmArgs &a, const HgPattern &p, uint32_t pi, const hgdev::lds_u32 *tab, uint64_t tile_start, uint64_t lo,
+                                                  uint64_t hi, uint32_t rank_lo, const HitSink &sink) {
+  if (lo >= hi) return;
+  const hgdev::lds_u32 *reach = tab + CT_REACH, *follow = tab + CT_FOLLOW, *amask = tab + CT_AMASK, *acct = tab + CT_ACC;
+  const uint8_t *text = a.text;
+  const uint32_t lead = p.max_len - 1;
+  uint64_t q = lo > lead ? lo - lead : 0;
+  uint32_t S[NW], I[NW];
+#pragma unroll
+  for (int u = 0; u < NW; u++) { S[u] = 0; I[u] = SIMPLE ? p.init_word : tab[CT_INIT + u]; }
+  uint32_t pc = HG_PC_START;
+  if (q) {
+    const uint32_t before = text[q - 1];
+    pc = (before == '\n' || before == 0) ? HG_PC_START : hg_prev_ctx(before);
+  }
+  uint32_t rank = rank_lo;     // newlines in [tile_start, position) once the walk is inside the own segment
+  bool reported = false;        // SINGLEMATCH: this lane already reported the current line
+  const bool single = p.single != 0;
+  const uint32_t id = p.id;
+  auto report = [&](uint64_t end, uint32_t rank_at_last) {  // match [.., end); its last byte end - 1 lies in [lo, hi)
+    if (single && reported) return;
+    reported = true;
+    const uint64_t pos = end - 1;
+    hgdev::PieceView pv;
+    if (!hgdev::piece_view(text, a.nbytes, a.sums, a.bases, a.bs1, pos, rank_at_last, pos, &pv)) return;
+    if (!pv.whole) return;  // cannot happen in a tile without forced breaks
+    const uint64_t z = text[pos] == '\n' ? end : hgdev::scanned_end(text, end, pv.limit);
+    sink.push(pv.line_no, id, static_cast<uint32_t>(end - pv.a), pv.a, static_cast<uint32_t>(z - pv.a), pi);
+  };
+  // p runs over [q, hi]; byte hi (if any) only lends its context to a match ending at hi
+  uint4 chunk = make_uint4(0, 0, 0, 0);
+  for (uint64_t pcur = q; pcur <= hi; pcur++) {
+    const bool at_end = pcur >= a.nbytes;
+    if (!at_end && ((pcur & 15u) == 0 || pcur == q)) chunk = *reinterpret_cast<const uint4 *>(text + (pcur & ~15ull));
+    const uint32_t c = at_end ? 0u : hgdev::byte_of(chunk, static_cast<uint32_t>(pcur & 15u));
+    const bool own_end = pcur > lo;  // a match ending at pcur has its last byte in the own segment
+    if (!SIMPLE) {
+      // a match can end before this byte; the byte decides the right-hand context (END at a NUL / the end of the text)
+      const uint32_t cc = (at_end || c == 0) ? HG_NC_END : (c == '\n' ? HG_NC_NLFINAL : (hg_is_word(c) ? HG_NC_WORD : HG_NC_OTHER));
+      uint32_t hit = 0;
+#pragma unroll
+      for (int u = 0; u < NW; u++) hit |= S[u] & acct[(pc * 5 + cc) * NW + u];
+      if (hit && own_end) report(pcur, rank);
+    }
+    if (pcur == hi || at_end) break;
+    if (c == 0) {  // scanned bytes end here (or leading NULs are skipped): start afresh after it
+#pragma unroll
+      for (int u = 0; u < NW; u++) S[u] = 0;
+      pc = HG_PC_START;
+      continue;
+    }
+    const uint32_t rank_here = rank;
+    {
+      uint32_t T[NW];
+#pragma unroll
+      for (int u = 0; u < NW; u++) T[u] = I[u];
+#pragma unroll
+      for (int u = 0; u < NW; u++)
+        for (uint32_t x = S[u]; x; x &= x - 1) {
+          const hgdev::lds_u32 *f = follow + (u * 32 + (__ffs(x) - 1)) * NW;
+#pragma unroll
+          for (int t = 0; t < NW; t++) T[t] |= f[t];
+        }
+      if (SIMPLE) {
+        S[0] = T[0] & reach[c];
+      } else {
+        const uint32_t cc = c == '\n' ? HG_NC_NLFINAL : (hg_is_word(c) ? HG_NC_WORD : HG_NC_OTHER);
+#pragma unroll
+        for (int u = 0; u < NW; u++) S[u] = T[u] & reach[c * NW + u] & amask[(pc * 4 + cc) * NW + u];
+      }
+    }
+    if (pcur >= lo && c == '\n') rank++;
+    if (SIMPLE) {
+      if ((S[0] & p.acc_all) && pcur >= lo) report(pcur + 1, rank_here);
+    }
+    if (c == '\n') {
+      if (!SIMPLE) {  // a match that includes the newline ends the line: END context
+        uint32_t hit = 0;
+#pragma unroll
+        for (int u = 0; u < NW; u++) hit |= S[u] & acct[(hg_prev_ctx(c) * 5 + HG_NC_END) * NW + u];
+        if (hit && pcur >= lo) report(pcur + 1, rank_here);
+      }
+#pragma unroll
+      for (int u = 0; u < NW; u++) S[u] = 0;
+      pc = HG_PC_START;
+      reported = false;
+    } else {
+      pc = hg_prev_ctx(c);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void hg_always_on_fast_kernel(HgConfirmArgs a) {
+  __shared__ uint32_t s_n, s_base;
+  __shared__ __attribute__((aligned(16))) uint32_t s_tab[4 * CT_WORDS];
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
+  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n};
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  hgdev::lds_u32 *tab = (hgdev::lds_u32 *)(&s_tab[0]) + wave * CT_WORDS;
+  const uint64_t waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
+  for (uint64_t tile = a.tile_begin + ((static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6); tile < a.tile_end; tile += waves) {
+    const uint64_t tile_start = tile << HG_TILE_SHIFT;
+    const uint64_t tile_stop = tile_start + HG_TILE_BYTES < a.nbytes ? tile_start + HG_TILE_BYTES : a.nbytes;
+    const uint64_t lo = tile_start + lane * 256ull < a.nbytes ? tile_start + lane * 256ull : a.nbytes;
+    const uint64_t hi = lo + 256 < a.nbytes ? lo + 256 : a.nbytes;
+    // newlines per segment -> rank of the segment start (aligned 16-byte chunks, SWAR)
+    uint32_t cnt = 0;
+    for (uint64_t chunk = lo; chunk < hi; chunk += 16) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(a.text + chunk);
+      uint32_t m = hgdev::eq_mask16(v, 0x0a0a0a0au);
+      if (hi - chunk < 16) m &= (1u << static_cast<uint32_t>(hi - chunk)) - 1u;
+      cnt += __popc(m);
+    }
+    const uint32_t rank_lo = wave_inclusive_scan(cnt, lane) - cnt;
+    const HgTileBase tb = a.bases[tile];
+    const bool plain = tile_stop - tb.cs <= a.bs1;  // no forced break of an over-long line inside this tile (wave-uniform)
+    if (!plain) {
+      uint32_t rank = rank_lo;
+      for (uint64_t s = lo; s < hi; s++) {
+        const bool starts = s == 0 || a.text[s - 1] == '\n';
+        if (starts)
+          hg_scan_line_always_on(a.db, a.text, a.nbytes, a.sums, a.bases, a.bs1, s, rank, 0u, a.db.nslow_fast,
+                                 [&](uint32_t pi, uint64_t line_no, uint32_t to, uint64_t start, uint32_t len) {
+                                   sink.push(line_no, a.db.patterns[pi].id, to, start, len, pi);
+                                 });
+        rank += a.text[s] == '\n';
+      }
+      continue;
+    }
+    for (uint32_t j = 0; j < a.db.nslow_fast; j++) {  // wave-uniform
+      const uint32_t pi = a.db.slow[j];
+      const HgPattern &p = a.db.patterns[pi];
+      const bool simple = p.simple != 0;
+      __builtin_amdgcn_wave_barrier();  // the previous pattern's tables are no longer read
+      if (simple) stage_tables<false>(tab, a.db.pool, p, 1u, lane);
+      else stage_tables<true>(tab, a.db.pool, p, p.nw, lane);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (simple) always_on_segment<1, true>(a, p, pi, tab, tile_start, lo, hi, rank_lo, sink);
+      else if (p.nw == 1) always_on_segment<1, false>(a, p, pi, tab, tile_start, lo, hi, rank_lo, sink);
+      else always_on_segment<2, false>(a, p, pi, tab, tile_start, lo, hi, rank_lo, sink);
     }
   }
   flush_hits(a, &s_n, &s_base);

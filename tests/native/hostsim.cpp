@@ -130,6 +130,7 @@ static HgDbView view_of(HgDb *db) {
   v.slow = db->slow.data();
   v.npatterns = db->patterns.size();
   v.nslow = db->slow.size();
+  v.nslow_fast = db->nslow_fast;
   v.fold_mask = db->fold_mask;
   return v;
 }
@@ -247,7 +248,7 @@ long hgsim_scan(void *h, const uint8_t *data, uint64_t nbytes, int buffer_size, 
       for (uint64_t s = base; s < end; s++) {
         bool starts = (s == 0) || data[s - 1] == '\n';
         if (starts)
-          hg_scan_line_always_on(v, data, nbytes, sums.data(), bases.data(), bs1, s, rank,
+          hg_scan_line_always_on(v, data, nbytes, sums.data(), bases.data(), bs1, s, rank, 0u, v.nslow,
                                  [&](uint32_t pi, uint64_t line_no, uint32_t to, uint64_t a, uint32_t len) {
                                    hits.push_back(HgHit{line_no, db->patterns[pi].id, to});
                                    aux.push_back(HgHitAux{a, len, pi});

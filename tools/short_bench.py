@@ -1,0 +1,19 @@
+import sys, time
+sys.path.insert(0, '/root/repo')
+import torch
+from hypergrep_amd import benchspec, device
+patterns, needles, hpm = benchspec.c3_spec()
+for pats in (["ERROR"], ["foo|bar"], ["status=5[0-9]{2}"], ["ERROR", "WARN", "panic", "fail"]):
+    nbytes = 1 << 30
+    text = torch.empty(nbytes + 64, dtype=torch.uint8, device="cuda:0")
+    device.synth_device(text.data_ptr(), nbytes, 77, needles, hpm)
+    torch.cuda.synchronize()
+    db = device.Database(pats, ids=list(range(len(pats))))
+    print(pats, db.info())
+    sc = device.Scanner(db, 0)
+    sc.scan(text.data_ptr(), nbytes)
+    t = time.perf_counter()
+    for _ in range(3):
+        st = sc.scan(text.data_ptr(), nbytes)
+    dt = (time.perf_counter() - t) / 3
+    print(f"  {nbytes / (1 << 30) / dt:8.1f} GiB/s  hits={st.n_hits} lines={st.n_lines}")
