@@ -960,14 +960,30 @@ __global__ __launch_bounds__(256) void hg_always_on_kernel(HgConfirmArgs a, uint
 // line; the ordering pass keeps the smallest end offset.  Tiles in which a forced break of an over-long line falls
 // (carry-in line start more than buffer_size - 1 bytes before the tile end) go through the scalar routine instead.
 // Tables: one pattern at a time, staged per wave in LDS like the automaton confirm routines.
+// One reported match [.., end): locate the line (LineHead: start, first scanned byte, NUL rules) and push the hit.  Out
+// of line: the scan loop is unrolled 16-fold.
+__device__ __noinline__ void always_on_report(const HgConfirmArgs &a, const HitSink &sink, uint32_t id, uint32_t pi, uint64_t end, uint32_t rank_at_last) {
+  const uint64_t pos = end - 1;  // the match's last byte; rank_at_last = newlines of the tile before it
+  hgdev::PieceView pv;
+  if (!hgdev::piece_view(a.text, a.nbytes, a.sums, a.bases, a.bs1, pos, rank_at_last, pos, &pv)) return;
+  if (!pv.whole) return;  // cannot happen in a tile without forced breaks
+  const uint64_t z = a.text[pos] == '\n' ? end : hgdev::scanned_end(a.text, end, pv.limit);
+  sink.push(pv.line_no, id, static_cast<uint32_t>(end - pv.a), pv.a, static_cast<uint32_t>(z - pv.a), pi);
+}
+
 template <int NW, bool SIMPLE>
-__device__ __forceinline__ void always_on_segment(const HgConfirmArgs &a, const HgPattern &p, uint32_t pi, const hgdev::lds_u32 *tab, uint64_t tile_start, uint64_t lo,
-                                                  uint64_t hi, uint32_t rank_lo, const HitSink &sink) {
+__device__ __forceinline__ void always_on_segment(const HgConfirmArgs &a, const HgPattern &p, uint32_t pi, const hgdev::lds_u32 *tab, uint64_t lo, uint64_t hi,
+                                                  uint32_t rank_lo, const HitSink &sink) {
   if (lo >= hi) return;
   const hgdev::lds_u32 *reach = tab + CT_REACH, *follow = tab + CT_FOLLOW, *amask = tab + CT_AMASK, *acct = tab + CT_ACC;
   const uint8_t *text = a.text;
   const uint32_t lead = p.max_len - 1;
-  uint64_t q = lo > lead ? lo - lead : 0;
+  const uint64_t q = lo > lead ? lo - lead : 0;  // first byte the automaton sees
+  const uint64_t base = q & ~15ull;
+  // offsets relative to base (all < 16 + 63 + 256 + 1): [first, stop) are consumed; `own` = first offset of the own segment;
+  // the byte at `stop` (if inside the text) only lends its context to a match ending there
+  const uint32_t first = static_cast<uint32_t>(q - base), own = static_cast<uint32_t>(lo - base), stop = static_cast<uint32_t>(hi - base);
+  const bool text_ends = hi >= a.nbytes;  // the byte at `stop` does not exist
   uint32_t S[NW], I[NW];
 #pragma unroll
   for (int u = 0; u < NW; u++) { S[u] = 0; I[u] = SIMPLE ? p.init_word : tab[CT_INIT + u]; }
@@ -976,44 +992,36 @@ __device__ __forceinline__ void always_on_segment(const HgConfirmArgs &a, const 
     const uint32_t before = text[q - 1];
     pc = (before == '\n' || before == 0) ? HG_PC_START : hg_prev_ctx(before);
   }
-  uint32_t rank = rank_lo;     // newlines in [tile_start, position) once the walk is inside the own segment
-  bool reported = false;        // SINGLEMATCH: this lane already reported the current line
+  uint32_t rank = rank_lo;  // newlines in [tile start, current byte) once the walk is inside the own segment
+  bool reported = false;    // SINGLEMATCH: this lane already reported the current line
   const bool single = p.single != 0;
-  const uint32_t id = p.id;
-  auto report = [&](uint64_t end, uint32_t rank_at_last) {  // match [.., end); its last byte end - 1 lies in [lo, hi)
-    if (single && reported) return;
-    reported = true;
-    const uint64_t pos = end - 1;
-    hgdev::PieceView pv;
-    if (!hgdev::piece_view(text, a.nbytes, a.sums, a.bases, a.bs1, pos, rank_at_last, pos, &pv)) return;
-    if (!pv.whole) return;  // cannot happen in a tile without forced breaks
-    const uint64_t z = text[pos] == '\n' ? end : hgdev::scanned_end(text, end, pv.limit);
-    sink.push(pv.line_no, id, static_cast<uint32_t>(end - pv.a), pv.a, static_cast<uint32_t>(z - pv.a), pi);
-  };
-  // p runs over [q, hi]; byte hi (if any) only lends its context to a match ending at hi
-  uint4 chunk = make_uint4(0, 0, 0, 0);
-  for (uint64_t pcur = q; pcur <= hi; pcur++) {
-    const bool at_end = pcur >= a.nbytes;
-    if (!at_end && ((pcur & 15u) == 0 || pcur == q)) chunk = *reinterpret_cast<const uint4 *>(text + (pcur & ~15ull));
-    const uint32_t c = at_end ? 0u : hgdev::byte_of(chunk, static_cast<uint32_t>(pcur & 15u));
-    const bool own_end = pcur > lo;  // a match ending at pcur has its last byte in the own segment
-    if (!SIMPLE) {
-      // a match can end before this byte; the byte decides the right-hand context (END at a NUL / the end of the text)
-      const uint32_t cc = (at_end || c == 0) ? HG_NC_END : (c == '\n' ? HG_NC_NLFINAL : (hg_is_word(c) ? HG_NC_WORD : HG_NC_OTHER));
-      uint32_t hit = 0;
+  const uint32_t id = p.id, acc_all = p.acc_all;
+  for (uint32_t off = 0; off <= stop; off += 16) {
+    const uint4 v = base + off < a.nbytes ? *reinterpret_cast<const uint4 *>(text + base + off) : make_uint4(0, 0, 0, 0);
 #pragma unroll
-      for (int u = 0; u < NW; u++) hit |= S[u] & acct[(pc * 5 + cc) * NW + u];
-      if (hit && own_end) report(pcur, rank);
-    }
-    if (pcur == hi || at_end) break;
-    if (c == 0) {  // scanned bytes end here (or leading NULs are skipped): start afresh after it
+    for (uint32_t i = 0; i < 16; i++) {
+      const uint32_t r = off + i;
+      if (r < first || r > stop) continue;
+      const bool beyond = r == stop;  // context only (or the end of the text)
+      const uint32_t c = (beyond && text_ends) ? 0u : hgdev::byte_of(v, i);
+      if (!SIMPLE) {
+        // a match can end before this byte; the byte decides the right-hand context (END at a NUL / the end of the text)
+        const uint32_t cc = c == 0 ? HG_NC_END : (c == '\n' ? HG_NC_NLFINAL : (hg_is_word(c) ? HG_NC_WORD : HG_NC_OTHER));
+        uint32_t hit = 0;
 #pragma unroll
-      for (int u = 0; u < NW; u++) S[u] = 0;
-      pc = HG_PC_START;
-      continue;
-    }
-    const uint32_t rank_here = rank;
-    {
+        for (int u = 0; u < NW; u++) hit |= S[u] & acct[(pc * 5 + cc) * NW + u];
+        if (hit && r > own && !(single && reported)) {
+          reported = true;
+          always_on_report(a, sink, id, pi, base + r, rank);
+        }
+      }
+      if (beyond) continue;
+      if (c == 0) {  // scanned bytes end here (or leading NULs are skipped): start afresh after it
+#pragma unroll
+        for (int u = 0; u < NW; u++) S[u] = 0;
+        pc = HG_PC_START;
+        continue;
+      }
       uint32_t T[NW];
 #pragma unroll
       for (int u = 0; u < NW; u++) T[u] = I[u];
@@ -1026,29 +1034,30 @@ __device__ __forceinline__ void always_on_segment(const HgConfirmArgs &a, const 
         }
       if (SIMPLE) {
         S[0] = T[0] & reach[c];
+        if ((S[0] & acc_all) && r >= own && !(single && reported)) {
+          reported = true;
+          always_on_report(a, sink, id, pi, base + r + 1, rank);
+        }
       } else {
         const uint32_t cc = c == '\n' ? HG_NC_NLFINAL : (hg_is_word(c) ? HG_NC_WORD : HG_NC_OTHER);
 #pragma unroll
         for (int u = 0; u < NW; u++) S[u] = T[u] & reach[c * NW + u] & amask[(pc * 4 + cc) * NW + u];
       }
-    }
-    if (pcur >= lo && c == '\n') rank++;
-    if (SIMPLE) {
-      if ((S[0] & p.acc_all) && pcur >= lo) report(pcur + 1, rank_here);
-    }
-    if (c == '\n') {
-      if (!SIMPLE) {  // a match that includes the newline ends the line: END context
-        uint32_t hit = 0;
+      if (c == '\n') {
+        if (!SIMPLE) {  // a match that includes the newline ends the line: END context
+          uint32_t hit = 0;
 #pragma unroll
-        for (int u = 0; u < NW; u++) hit |= S[u] & acct[(hg_prev_ctx(c) * 5 + HG_NC_END) * NW + u];
-        if (hit && pcur >= lo) report(pcur + 1, rank_here);
+          for (int u = 0; u < NW; u++) hit |= S[u] & acct[(HG_PC_NL * 5 + HG_NC_END) * NW + u];
+          if (hit && r >= own && !(single && reported)) always_on_report(a, sink, id, pi, base + r + 1, rank);
+        }
+        if (r >= own) rank++;
+#pragma unroll
+        for (int u = 0; u < NW; u++) S[u] = 0;
+        pc = HG_PC_START;
+        reported = false;
+      } else {
+        pc = hg_prev_ctx(c);
       }
-#pragma unroll
-      for (int u = 0; u < NW; u++) S[u] = 0;
-      pc = HG_PC_START;
-      reported = false;
-    } else {
-      pc = hg_prev_ctx(c);
     }
   }
 }
@@ -1101,9 +1110,9 @@ __global__ __launch_bounds__(256) void hg_always_on_fast_kernel(HgConfirmArgs a)
       else stage_tables<true>(tab, a.db.pool, p, p.nw, lane);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      if (simple) always_on_segment<1, true>(a, p, pi, tab, tile_start, lo, hi, rank_lo, sink);
-      else if (p.nw == 1) always_on_segment<1, false>(a, p, pi, tab, tile_start, lo, hi, rank_lo, sink);
-      else always_on_segment<2, false>(a, p, pi, tab, tile_start, lo, hi, rank_lo, sink);
+      if (simple) always_on_segment<1, true>(a, p, pi, tab, lo, hi, rank_lo, sink);
+      else if (p.nw == 1) always_on_segment<1, false>(a, p, pi, tab, lo, hi, rank_lo, sink);
+      else always_on_segment<2, false>(a, p, pi, tab, lo, hi, rank_lo, sink);
     }
   }
   flush_hits(a, &s_n, &s_base);
