@@ -22,7 +22,7 @@ __global__ void hg_tile_inner_kernel(const uint8_t *text, HgTileSum *sums, uint6
 __global__ void hg_verify_kernel(HgConfirmArgs a);
 __global__ void hg_confirm_fast_kernel(HgConfirmArgs a, uint32_t blocks_per_mode);
 __global__ void hg_confirm_generic_kernel(HgConfirmArgs a);
-__global__ void hg_always_on_kernel(HgConfirmArgs a, uint32_t first, uint32_t last);
+__global__ void hg_always_on_kernel(HgConfirmArgs a, uint32_t first, uint32_t last, uint32_t broken_only);
 __global__ void hg_always_on_fast_kernel(HgConfirmArgs a);
 __global__ void hg_block_mark_kernel(HgConfirmArgs a, uint32_t *pattern_flags);
 __global__ void hg_block_scan_kernel(HgConfirmArgs a, const uint32_t *pattern_flags);
@@ -374,8 +374,11 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
           always_blocks = static_cast<uint32_t>(std::min<uint64_t>((span + 3) / 4, static_cast<uint64_t>(num_cus_) * 8));
           ca.hit_seg_cap = hit_cap_ / always_blocks;
           const uint32_t nfast = db_->nslow_fast, nall = static_cast<uint32_t>(db_->slow.size());
-          if (nfast) hipLaunchKernelGGL(hg_always_on_fast_kernel, dim3(always_blocks), dim3(256), 0, side, ca);
-          if (nall > nfast) hipLaunchKernelGGL(hg_always_on_kernel, dim3(always_blocks), dim3(256), 0, side, ca, nfast, nall);
+          if (nfast) {
+            hipLaunchKernelGGL(hg_always_on_fast_kernel, dim3(always_blocks), dim3(256), 0, side, ca);
+            hipLaunchKernelGGL(hg_always_on_kernel, dim3(always_blocks), dim3(256), 0, side, ca, 0u, nfast, 1u);  // tiles with forced line breaks
+          }
+          if (nall > nfast) hipLaunchKernelGGL(hg_always_on_kernel, dim3(always_blocks), dim3(256), 0, side, ca, nfast, nall, 0u);
           HG_TRY(hipGetLastError(), "hg_always_on_kernel launch");
         }
       }

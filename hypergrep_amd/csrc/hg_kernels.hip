@@ -923,8 +923,9 @@ __global__ __launch_bounds__(HG_CONFIRM_THREADS) void hg_confirm_fast_kernel(HgC
 __global__ __launch_bounds__(256) void hg_confirm_generic_kernel(HgConfirmArgs a) { confirm_body<3>(a, blockIdx.x, gridDim.x); }
 
 // Always-on tier: one wave per tile, each lane owns 256 bytes and handles the lines that START there.
-// Scalar always-on pass over the entries [first, last) of the always-on list.
-__global__ __launch_bounds__(256) void hg_always_on_kernel(HgConfirmArgs a, uint32_t first, uint32_t last) {
+// Scalar always-on pass over the entries [first, last) of the always-on list.  broken_only: just the tiles the segment-parallel
+// kernel leaves out (a forced break of an over-long line falls inside them).
+__global__ __launch_bounds__(256) void hg_always_on_kernel(HgConfirmArgs a, uint32_t first, uint32_t last, uint32_t broken_only) {
   __shared__ uint32_t s_n, s_base;
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
@@ -933,6 +934,11 @@ __global__ __launch_bounds__(256) void hg_always_on_kernel(HgConfirmArgs a, uint
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
   for (uint64_t tile = a.tile_begin + ((static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6); tile < a.tile_end; tile += waves) {
+    if (broken_only) {
+      const uint64_t tile_start = tile << HG_TILE_SHIFT;
+      const uint64_t tile_stop = tile_start + HG_TILE_BYTES < a.nbytes ? tile_start + HG_TILE_BYTES : a.nbytes;
+      if (tile_stop - a.bases[tile].cs <= a.bs1) continue;
+    }
     const uint64_t lo = (tile << HG_TILE_SHIFT) + lane * 256ull;
     uint64_t hi = lo + 256;
     if (hi > a.nbytes) hi = a.nbytes;
@@ -962,18 +968,34 @@ __global__ __launch_bounds__(256) void hg_always_on_kernel(HgConfirmArgs a, uint
 // Tables: one pattern at a time, staged per wave in LDS like the automaton confirm routines.
 // One reported match [.., end): locate the line (LineHead: start, first scanned byte, NUL rules) and push the hit.  Out
 // of line: the scan loop is unrolled 16-fold.
-__device__ __noinline__ void always_on_report(const HgConfirmArgs &a, const HitSink &sink, uint32_t id, uint32_t pi, uint64_t end, uint32_t rank_at_last) {
+// (everything by value: a reference to the kernel's argument struct would move it to scratch and turn every load of the
+// scan loop into a flat load)
+struct AlwaysOnCtx {
+  const uint8_t *text;
+  uint64_t nbytes, bs1;
+  const HgTileSum *sums;
+  const HgTileBase *bases;
+  HgHit *seg_hits;
+  HgHitAux *seg_aux;
+  uint32_t seg_cap;
+  hgdev::lds_u32 *hit_count;
+};
+__device__ __noinline__ void always_on_report(const AlwaysOnCtx cx, uint32_t id, uint32_t pi, uint64_t end, uint32_t rank_at_last) {
   const uint64_t pos = end - 1;  // the match's last byte; rank_at_last = newlines of the tile before it
   hgdev::PieceView pv;
-  if (!hgdev::piece_view(a.text, a.nbytes, a.sums, a.bases, a.bs1, pos, rank_at_last, pos, &pv)) return;
+  if (!hgdev::piece_view(cx.text, cx.nbytes, cx.sums, cx.bases, cx.bs1, pos, rank_at_last, pos, &pv)) return;
   if (!pv.whole) return;  // cannot happen in a tile without forced breaks
-  const uint64_t z = a.text[pos] == '\n' ? end : hgdev::scanned_end(a.text, end, pv.limit);
-  sink.push(pv.line_no, id, static_cast<uint32_t>(end - pv.a), pv.a, static_cast<uint32_t>(z - pv.a), pi);
+  const uint64_t z = cx.text[pos] == '\n' ? end : hgdev::scanned_end(cx.text, end, pv.limit);
+  const uint32_t slot = __hip_atomic_fetch_add(cx.hit_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (slot < cx.seg_cap) {
+    cx.seg_hits[slot] = HgHit{pv.line_no, id, static_cast<uint32_t>(end - pv.a)};
+    cx.seg_aux[slot] = HgHitAux{pv.a, static_cast<uint32_t>(z - pv.a), pi};
+  }
 }
 
 template <int NW, bool SIMPLE>
-__device__ __forceinline__ void always_on_segment(const HgConfirmArgs &a, const HgPattern &p, uint32_t pi, const hgdev::lds_u32 *tab, uint64_t lo, uint64_t hi,
-                                                  uint32_t rank_lo, const HitSink &sink) {
+__device__ __forceinline__ void always_on_segment(const AlwaysOnCtx &a, const HgPattern &p, uint32_t pi, const hgdev::lds_u32 *tab, uint64_t lo, uint64_t hi,
+                                                  uint32_t rank_lo) {
   if (lo >= hi) return;
   const hgdev::lds_u32 *reach = tab + CT_REACH, *follow = tab + CT_FOLLOW, *amask = tab + CT_AMASK, *acct = tab + CT_ACC;
   const uint8_t *text = a.text;
@@ -998,6 +1020,13 @@ __device__ __forceinline__ void always_on_segment(const HgConfirmArgs &a, const 
   const uint32_t id = p.id, acc_all = p.acc_all;
   for (uint32_t off = 0; off <= stop; off += 16) {
     const uint4 v = base + off < a.nbytes ? *reinterpret_cast<const uint4 *>(text + base + off) : make_uint4(0, 0, 0, 0);
+    // the reach sets of the 16 bytes do not depend on the automaton state: fetch them ahead of the dependent chain
+    // (one-word automata; with two words the 32 values would halve the occupancy)
+    uint32_t rc[NW == 1 ? 16 : 1];
+    if (NW == 1) {
+#pragma unroll
+      for (uint32_t i = 0; i < 16; i++) rc[i] = reach[hgdev::byte_of(v, i)];
+    }
 #pragma unroll
     for (uint32_t i = 0; i < 16; i++) {
       const uint32_t r = off + i;
@@ -1012,7 +1041,7 @@ __device__ __forceinline__ void always_on_segment(const HgConfirmArgs &a, const 
         for (int u = 0; u < NW; u++) hit |= S[u] & acct[(pc * 5 + cc) * NW + u];
         if (hit && r > own && !(single && reported)) {
           reported = true;
-          always_on_report(a, sink, id, pi, base + r, rank);
+          always_on_report(a, id, pi, base + r, rank);
         }
       }
       if (beyond) continue;
@@ -1033,22 +1062,22 @@ __device__ __forceinline__ void always_on_segment(const HgConfirmArgs &a, const 
           for (int t = 0; t < NW; t++) T[t] |= f[t];
         }
       if (SIMPLE) {
-        S[0] = T[0] & reach[c];
+        S[0] = T[0] & rc[i];
         if ((S[0] & acc_all) && r >= own && !(single && reported)) {
           reported = true;
-          always_on_report(a, sink, id, pi, base + r + 1, rank);
+          always_on_report(a, id, pi, base + r + 1, rank);
         }
       } else {
         const uint32_t cc = c == '\n' ? HG_NC_NLFINAL : (hg_is_word(c) ? HG_NC_WORD : HG_NC_OTHER);
 #pragma unroll
-        for (int u = 0; u < NW; u++) S[u] = T[u] & reach[c * NW + u] & amask[(pc * 4 + cc) * NW + u];
+        for (int u = 0; u < NW; u++) S[u] = T[u] & (NW == 1 ? rc[NW == 1 ? i : 0] : reach[c * NW + u]) & amask[(pc * 4 + cc) * NW + u];
       }
       if (c == '\n') {
         if (!SIMPLE) {  // a match that includes the newline ends the line: END context
           uint32_t hit = 0;
 #pragma unroll
           for (int u = 0; u < NW; u++) hit |= S[u] & acct[(HG_PC_NL * 5 + HG_NC_END) * NW + u];
-          if (hit && r >= own && !(single && reported)) always_on_report(a, sink, id, pi, base + r + 1, rank);
+          if (hit && r >= own && !(single && reported)) always_on_report(a, id, pi, base + r + 1, rank);
         }
         if (r >= own) rank++;
 #pragma unroll
@@ -1071,6 +1100,7 @@ __global__ __launch_bounds__(256) void hg_always_on_fast_kernel(HgConfirmArgs a)
   const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n};
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   hgdev::lds_u32 *tab = (hgdev::lds_u32 *)(&s_tab[0]) + wave * CT_WORDS;
+  const AlwaysOnCtx cx{a.text, a.nbytes, a.bs1, a.sums, a.bases, a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, (hgdev::lds_u32 *)(&s_n)};
   const uint64_t waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
   for (uint64_t tile = a.tile_begin + ((static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6); tile < a.tile_end; tile += waves) {
     const uint64_t tile_start = tile << HG_TILE_SHIFT;
@@ -1088,19 +1118,7 @@ __global__ __launch_bounds__(256) void hg_always_on_fast_kernel(HgConfirmArgs a)
     const uint32_t rank_lo = wave_inclusive_scan(cnt, lane) - cnt;
     const HgTileBase tb = a.bases[tile];
     const bool plain = tile_stop - tb.cs <= a.bs1;  // no forced break of an over-long line inside this tile (wave-uniform)
-    if (!plain) {
-      uint32_t rank = rank_lo;
-      for (uint64_t s = lo; s < hi; s++) {
-        const bool starts = s == 0 || a.text[s - 1] == '\n';
-        if (starts)
-          hg_scan_line_always_on(a.db, a.text, a.nbytes, a.sums, a.bases, a.bs1, s, rank, 0u, a.db.nslow_fast,
-                                 [&](uint32_t pi, uint64_t line_no, uint32_t to, uint64_t start, uint32_t len) {
-                                   sink.push(line_no, a.db.patterns[pi].id, to, start, len, pi);
-                                 });
-        rank += a.text[s] == '\n';
-      }
-      continue;
-    }
+    if (!plain) continue;  // hg_always_on_kernel(broken_only) takes this tile
     for (uint32_t j = 0; j < a.db.nslow_fast; j++) {  // wave-uniform
       const uint32_t pi = a.db.slow[j];
       const HgPattern &p = a.db.patterns[pi];
@@ -1110,9 +1128,9 @@ __global__ __launch_bounds__(256) void hg_always_on_fast_kernel(HgConfirmArgs a)
       else stage_tables<true>(tab, a.db.pool, p, p.nw, lane);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      if (simple) always_on_segment<1, true>(a, p, pi, tab, lo, hi, rank_lo, sink);
-      else if (p.nw == 1) always_on_segment<1, false>(a, p, pi, tab, lo, hi, rank_lo, sink);
-      else always_on_segment<2, false>(a, p, pi, tab, lo, hi, rank_lo, sink);
+      if (simple) always_on_segment<1, true>(cx, p, pi, tab, lo, hi, rank_lo);
+      else if (p.nw == 1) always_on_segment<1, false>(cx, p, pi, tab, lo, hi, rank_lo);
+      else always_on_segment<2, false>(cx, p, pi, tab, lo, hi, rank_lo);
     }
   }
   flush_hits(a, &s_n, &s_base);
