@@ -65,6 +65,8 @@ struct HgConfirmArgs {
   uint32_t *defer_count;  // entries appended to each list, indexed mode * HG_DEFER_SHARDS + shard
   uint32_t list_of_mode[HG_CONFIRM_MODES];
   uint32_t mode_present[HG_CONFIRM_MODES];
+  uint32_t *always_count;                 // matches noted per block (reuses the chunk's candidate segment counts)
+  uint32_t always_list_cap;               // entries per block of the always-on match list (it reuses `deferred`)
   uint32_t list_spread[HG_CONFIRM_MODES];  // automaton modes: lists per pattern (few patterns: each is spread over several lists)
   uint32_t cand_seg_cap, hit_cap, hit_seg_cap, defer_shard_cap;
   uint32_t *counters;

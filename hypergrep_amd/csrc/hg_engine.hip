@@ -24,6 +24,7 @@ __global__ void hg_confirm_fast_kernel(HgConfirmArgs a, uint32_t blocks_per_mode
 __global__ void hg_confirm_generic_kernel(HgConfirmArgs a);
 __global__ void hg_always_on_kernel(HgConfirmArgs a, uint32_t first, uint32_t last, uint32_t broken_only);
 __global__ void hg_always_on_fast_kernel(HgConfirmArgs a);
+__global__ void hg_always_on_finish_kernel(HgConfirmArgs a);
 __global__ void hg_block_mark_kernel(HgConfirmArgs a, uint32_t *pattern_flags);
 __global__ void hg_block_scan_kernel(HgConfirmArgs a, const uint32_t *pattern_flags);
 __global__ void hg_key_kernel(const HgHit *hits, const HgHitAux *aux, const HgPattern *patterns, uint32_t n, uint64_t *key, uint32_t *idx);
@@ -375,7 +376,12 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
           ca.hit_seg_cap = hit_cap_ / always_blocks;
           const uint32_t nfast = db_->nslow_fast, nall = static_cast<uint32_t>(db_->slow.size());
           if (nfast) {
+            // the match list lives in the (by now idle) verified-occurrence lists: cand_cap_ entries at least, a segment per block
+            ca.deferred = d_deferred_;
+            ca.always_count = seg_count;  // this chunk's candidate segment counts were consumed by the verify pass
+            ca.always_list_cap = cand_cap_ / always_blocks;
             hipLaunchKernelGGL(hg_always_on_fast_kernel, dim3(always_blocks), dim3(256), 0, side, ca);
+            hipLaunchKernelGGL(hg_always_on_finish_kernel, dim3(always_blocks), dim3(256), 0, side, ca);
             hipLaunchKernelGGL(hg_always_on_kernel, dim3(always_blocks), dim3(256), 0, side, ca, 0u, nfast, 1u);  // tiles with forced line breaks
           }
           if (nall > nfast) hipLaunchKernelGGL(hg_always_on_kernel, dim3(always_blocks), dim3(256), 0, side, ca, nfast, nall, 0u);

@@ -966,31 +966,19 @@ __global__ __launch_bounds__(256) void hg_always_on_kernel(HgConfirmArgs a, uint
 // line; the ordering pass keeps the smallest end offset.  Tiles in which a forced break of an over-long line falls
 // (carry-in line start more than buffer_size - 1 bytes before the tile end) go through the scalar routine instead.
 // Tables: one pattern at a time, staged per wave in LDS like the automaton confirm routines.
-// One reported match [.., end): locate the line (LineHead: start, first scanned byte, NUL rules) and push the hit.  Out
-// of line: the scan loop is unrolled 16-fold.
-// (everything by value: a reference to the kernel's argument struct would move it to scratch and turn every load of the
-// scan loop into a flat load)
+// The scan loop only notes a match (end offset, pattern, newlines of the tile before its last byte) in the block's private
+// list; hg_always_on_finish_kernel locates the lines afterwards, every lane busy.  Keeping the line geometry (and its
+// registers) out of the scan kernel is what lets eight waves per SIMD hide the LDS latency of the automaton steps.
 struct AlwaysOnCtx {
   const uint8_t *text;
-  uint64_t nbytes, bs1;
-  const HgTileSum *sums;
-  const HgTileBase *bases;
-  HgHit *seg_hits;
-  HgHitAux *seg_aux;
-  uint32_t seg_cap;
-  hgdev::lds_u32 *hit_count;
+  uint64_t nbytes;
+  HgDeferred *list;            // this block's segment of the match list
+  uint32_t list_cap;
+  hgdev::lds_u32 *list_count;  // LDS counter of the block
 };
-__device__ __noinline__ void always_on_report(const AlwaysOnCtx cx, uint32_t id, uint32_t pi, uint64_t end, uint32_t rank_at_last) {
-  const uint64_t pos = end - 1;  // the match's last byte; rank_at_last = newlines of the tile before it
-  hgdev::PieceView pv;
-  if (!hgdev::piece_view(cx.text, cx.nbytes, cx.sums, cx.bases, cx.bs1, pos, rank_at_last, pos, &pv)) return;
-  if (!pv.whole) return;  // cannot happen in a tile without forced breaks
-  const uint64_t z = cx.text[pos] == '\n' ? end : hgdev::scanned_end(cx.text, end, pv.limit);
-  const uint32_t slot = __hip_atomic_fetch_add(cx.hit_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  if (slot < cx.seg_cap) {
-    cx.seg_hits[slot] = HgHit{pv.line_no, id, static_cast<uint32_t>(end - pv.a)};
-    cx.seg_aux[slot] = HgHitAux{pv.a, static_cast<uint32_t>(z - pv.a), pi};
-  }
+__device__ __forceinline__ void always_on_note(const AlwaysOnCtx &cx, uint32_t pi, uint64_t end, uint32_t rank_at_last) {
+  const uint32_t slot = __hip_atomic_fetch_add(cx.list_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (slot < cx.list_cap) cx.list[slot] = HgDeferred{end, pi, rank_at_last};
 }
 
 template <int NW, bool SIMPLE>
@@ -1017,22 +1005,25 @@ __device__ __forceinline__ void always_on_segment(const AlwaysOnCtx &a, const Hg
   uint32_t rank = rank_lo;  // newlines in [tile start, current byte) once the walk is inside the own segment
   bool reported = false;    // SINGLEMATCH: this lane already reported the current line
   const bool single = p.single != 0;
-  const uint32_t id = p.id, acc_all = p.acc_all;
-  for (uint32_t off = 0; off <= stop; off += 16) {
-    const uint4 v = base + off < a.nbytes ? *reinterpret_cast<const uint4 *>(text + base + off) : make_uint4(0, 0, 0, 0);
-    // the reach sets of the 16 bytes do not depend on the automaton state: fetch them ahead of the dependent chain
-    // (one-word automata; with two words the 32 values would halve the occupancy)
-    uint32_t rc[NW == 1 ? 16 : 1];
-    if (NW == 1) {
+  const uint32_t acc_all = p.acc_all;
+  uint4 chunk = make_uint4(0, 0, 0, 0);
+#pragma unroll 1
+  for (uint32_t off = 0; off <= stop; off += 4) {  // 16-byte loads, a dword per trip: the unrolled body (and its registers) stays small
+    if ((off & 15u) == 0) chunk = base + off < a.nbytes ? *reinterpret_cast<const uint4 *>(text + base + off) : make_uint4(0, 0, 0, 0);
+    const uint32_t sel = (off >> 2) & 3u;
+    const uint32_t v = sel == 0 ? chunk.x : (sel == 1 ? chunk.y : (sel == 2 ? chunk.z : chunk.w));
+    // the reach sets of the four bytes do not depend on the automaton state: fetch them ahead of the dependent chain
+    uint32_t rc[4][NW];
 #pragma unroll
-      for (uint32_t i = 0; i < 16; i++) rc[i] = reach[hgdev::byte_of(v, i)];
-    }
+    for (uint32_t i = 0; i < 4; i++)
 #pragma unroll
-    for (uint32_t i = 0; i < 16; i++) {
+      for (int u = 0; u < NW; u++) rc[i][u] = reach[((v >> (8 * i)) & 0xFFu) * NW + u];
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
       const uint32_t r = off + i;
       if (r < first || r > stop) continue;
       const bool beyond = r == stop;  // context only (or the end of the text)
-      const uint32_t c = (beyond && text_ends) ? 0u : hgdev::byte_of(v, i);
+      const uint32_t c = (beyond && text_ends) ? 0u : ((v >> (8 * i)) & 0xFFu);
       if (!SIMPLE) {
         // a match can end before this byte; the byte decides the right-hand context (END at a NUL / the end of the text)
         const uint32_t cc = c == 0 ? HG_NC_END : (c == '\n' ? HG_NC_NLFINAL : (hg_is_word(c) ? HG_NC_WORD : HG_NC_OTHER));
@@ -1041,7 +1032,7 @@ __device__ __forceinline__ void always_on_segment(const AlwaysOnCtx &a, const Hg
         for (int u = 0; u < NW; u++) hit |= S[u] & acct[(pc * 5 + cc) * NW + u];
         if (hit && r > own && !(single && reported)) {
           reported = true;
-          always_on_report(a, id, pi, base + r, rank);
+          always_on_note(a, pi, base + r, rank);
         }
       }
       if (beyond) continue;
@@ -1062,22 +1053,22 @@ __device__ __forceinline__ void always_on_segment(const AlwaysOnCtx &a, const Hg
           for (int t = 0; t < NW; t++) T[t] |= f[t];
         }
       if (SIMPLE) {
-        S[0] = T[0] & rc[i];
+        S[0] = T[0] & rc[i][0];
         if ((S[0] & acc_all) && r >= own && !(single && reported)) {
           reported = true;
-          always_on_report(a, id, pi, base + r + 1, rank);
+          always_on_note(a, pi, base + r + 1, rank);
         }
       } else {
         const uint32_t cc = c == '\n' ? HG_NC_NLFINAL : (hg_is_word(c) ? HG_NC_WORD : HG_NC_OTHER);
 #pragma unroll
-        for (int u = 0; u < NW; u++) S[u] = T[u] & (NW == 1 ? rc[NW == 1 ? i : 0] : reach[c * NW + u]) & amask[(pc * 4 + cc) * NW + u];
+        for (int u = 0; u < NW; u++) S[u] = T[u] & rc[i][u] & amask[(pc * 4 + cc) * NW + u];
       }
       if (c == '\n') {
         if (!SIMPLE) {  // a match that includes the newline ends the line: END context
           uint32_t hit = 0;
 #pragma unroll
           for (int u = 0; u < NW; u++) hit |= S[u] & acct[(HG_PC_NL * 5 + HG_NC_END) * NW + u];
-          if (hit && r >= own && !(single && reported)) always_on_report(a, id, pi, base + r + 1, rank);
+          if (hit && r >= own && !(single && reported)) always_on_note(a, pi, base + r + 1, rank);
         }
         if (r >= own) rank++;
 #pragma unroll
@@ -1092,15 +1083,15 @@ __device__ __forceinline__ void always_on_segment(const AlwaysOnCtx &a, const Hg
 }
 
 __global__ __launch_bounds__(256) void hg_always_on_fast_kernel(HgConfirmArgs a) {
-  __shared__ uint32_t s_n, s_base;
+  __shared__ uint32_t s_n;
   __shared__ __attribute__((aligned(16))) uint32_t s_tab[4 * CT_WORDS];
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
-  const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
-  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n};
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   hgdev::lds_u32 *tab = (hgdev::lds_u32 *)(&s_tab[0]) + wave * CT_WORDS;
-  const AlwaysOnCtx cx{a.text, a.nbytes, a.bs1, a.sums, a.bases, a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, (hgdev::lds_u32 *)(&s_n)};
+  // the verified-occurrence lists are free again (their confirm passes ran before this kernel): one segment per block
+  const uint32_t list_cap = a.always_list_cap;
+  const AlwaysOnCtx cx{a.text, a.nbytes, a.deferred + static_cast<uint64_t>(blockIdx.x) * list_cap, list_cap, (hgdev::lds_u32 *)(&s_n)};
   const uint64_t waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
   for (uint64_t tile = a.tile_begin + ((static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6); tile < a.tile_end; tile += waves) {
     const uint64_t tile_start = tile << HG_TILE_SHIFT;
@@ -1132,6 +1123,34 @@ __global__ __launch_bounds__(256) void hg_always_on_fast_kernel(HgConfirmArgs a)
       else if (p.nw == 1) always_on_segment<1, false>(cx, p, pi, tab, lo, hi, rank_lo);
       else always_on_segment<2, false>(cx, p, pi, tab, lo, hi, rank_lo);
     }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t n = s_n;
+    a.always_count[blockIdx.x] = n < list_cap ? n : list_cap;
+    // DEFER_NEED is in entries per list of HG_DEFER_SHARDS lists (the workspace grows to need * HG_DEFER_SHARDS entries)
+    if (n > list_cap) atomicMax(&a.counters[HG_CNT_DEFER_NEED], static_cast<uint32_t>((static_cast<uint64_t>(n) * gridDim.x + HG_DEFER_SHARDS - 1) / HG_DEFER_SHARDS));
+  }
+}
+
+// Matches noted by hg_always_on_fast_kernel -> hits: the line of the match's last byte (start, first scanned byte, NUL
+// rules: LineHead), the end of its scanned bytes, the hit record.
+__global__ __launch_bounds__(256) void hg_always_on_finish_kernel(HgConfirmArgs a) {
+  __shared__ uint32_t s_n, s_base;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
+  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n};
+  const HgDeferred *list = a.deferred + static_cast<uint64_t>(blockIdx.x) * a.always_list_cap;
+  const uint32_t n = a.always_count[blockIdx.x];
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const HgDeferred d = list[i];
+    const uint64_t end = d.pos, pos = end - 1;  // the match's last byte; d.rank = newlines of the tile before it
+    hgdev::PieceView pv;
+    if (!hgdev::piece_view(a.text, a.nbytes, a.sums, a.bases, a.bs1, pos, d.rank, pos, &pv)) continue;
+    if (!pv.whole) continue;  // cannot happen in a tile without forced breaks
+    const uint64_t z = a.text[pos] == '\n' ? end : hgdev::scanned_end(a.text, end, pv.limit);
+    sink.push(pv.line_no, a.db.patterns[d.pattern].id, static_cast<uint32_t>(end - pv.a), pv.a, static_cast<uint32_t>(z - pv.a), d.pattern);
   }
   flush_hits(a, &s_n, &s_base);
 }
