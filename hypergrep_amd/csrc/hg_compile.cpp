@@ -1351,11 +1351,11 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
     return -2;
   }
 
-  // always-on patterns of bounded length and at most two state words go first: the segment-parallel kernel takes those
+  // always-on patterns of at most two state words go first: the segment-parallel kernel takes those
   {
     auto fast = [&](uint32_t pi) {
       const HgPattern &p = db->patterns[pi];
-      return p.max_len >= 1 && p.max_len <= HG_ALWAYS_ON_FAST_MAX_LEN && p.nw <= 2;
+      return p.nw <= 2;  // bounded or not: an unbounded pattern's lead-in is the start of its line
     };
     std::stable_partition(db->slow.begin(), db->slow.end(), fast);
     db->nslow_fast = static_cast<uint32_t>(std::count_if(db->slow.begin(), db->slow.end(), fast));

@@ -54,7 +54,7 @@ struct HgDbView {
   const HgWindow *windows2;
   const uint32_t *slow;
   uint32_t npatterns, nslow, fold_mask;
-  uint32_t nslow_fast;  // the first nslow_fast entries of `slow` are bounded, <= 2 state words: hg_always_on_fast_kernel takes them
+  uint32_t nslow_fast;  // the first nslow_fast entries of `slow` have <= 2 state words: hg_always_on_fast_kernel takes them
 };
 
 // 0x80 in every byte of x that is zero, exact (no borrow between bytes).

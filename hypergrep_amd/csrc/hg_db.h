@@ -26,7 +26,7 @@ constexpr uint32_t HG_TT_ALL = (1u << 20) - 1;
 constexpr uint32_t HG_MAX_NODES = 1024;  // per pattern (32 state words)
 constexpr uint32_t HG_MAX_W = HG_MAX_NODES / 32;
 constexpr uint32_t HG_MAX_PATTERNS = 1u << 24;  // pattern index and window offset share one word in the verified-occurrence records
-constexpr uint32_t HG_ALWAYS_ON_FAST_MAX_LEN = 64;  // longest match of an always-on pattern the segment-parallel kernel takes
+constexpr uint32_t HG_ALWAYS_ON_FAST_MAX_LEN = 64;  // always-on patterns up to this match length use a fixed lead-in, longer / unbounded ones their line's start
 constexpr uint32_t HG_FACTOR_MAX = 32;   // bytes of a required literal kept for the in-stream verify
 // A window = the low HG_WINDOW_BYTES bytes of a dword-aligned text dword.  4 and 3 are supported; measured on the
 // round-1 workload a 3-byte window admits 6-byte literals to the fast tier but is hit 1.5x more often by filler text.

@@ -22,7 +22,7 @@ __global__ void hg_tile_inner_kernel(const uint8_t *text, HgTileSum *sums, uint6
 __global__ void hg_verify_kernel(HgConfirmArgs a);
 __global__ void hg_confirm_fast_kernel(HgConfirmArgs a, uint32_t blocks_per_mode);
 __global__ void hg_confirm_generic_kernel(HgConfirmArgs a);
-__global__ void hg_always_on_kernel(HgConfirmArgs a, uint32_t first, uint32_t last, uint32_t broken_only);
+__global__ void hg_always_on_kernel(HgConfirmArgs a, uint32_t first, uint32_t last);
 __global__ void hg_always_on_fast_kernel(HgConfirmArgs a);
 __global__ void hg_always_on_finish_kernel(HgConfirmArgs a);
 __global__ void hg_block_mark_kernel(HgConfirmArgs a, uint32_t *pattern_flags);
@@ -382,9 +382,8 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
             ca.always_list_cap = cand_cap_ / always_blocks;
             hipLaunchKernelGGL(hg_always_on_fast_kernel, dim3(always_blocks), dim3(256), 0, side, ca);
             hipLaunchKernelGGL(hg_always_on_finish_kernel, dim3(always_blocks), dim3(256), 0, side, ca);
-            hipLaunchKernelGGL(hg_always_on_kernel, dim3(always_blocks), dim3(256), 0, side, ca, 0u, nfast, 1u);  // tiles with forced line breaks
           }
-          if (nall > nfast) hipLaunchKernelGGL(hg_always_on_kernel, dim3(always_blocks), dim3(256), 0, side, ca, nfast, nall, 0u);
+          if (nall > nfast) hipLaunchKernelGGL(hg_always_on_kernel, dim3(always_blocks), dim3(256), 0, side, ca, nfast, nall);
           HG_TRY(hipGetLastError(), "hg_always_on_kernel launch");
         }
       }

@@ -923,9 +923,8 @@ __global__ __launch_bounds__(HG_CONFIRM_THREADS) void hg_confirm_fast_kernel(HgC
 __global__ __launch_bounds__(256) void hg_confirm_generic_kernel(HgConfirmArgs a) { confirm_body<3>(a, blockIdx.x, gridDim.x); }
 
 // Always-on tier: one wave per tile, each lane owns 256 bytes and handles the lines that START there.
-// Scalar always-on pass over the entries [first, last) of the always-on list.  broken_only: just the tiles the segment-parallel
-// kernel leaves out (a forced break of an over-long line falls inside them).
-__global__ __launch_bounds__(256) void hg_always_on_kernel(HgConfirmArgs a, uint32_t first, uint32_t last, uint32_t broken_only) {
+// Scalar always-on pass over the entries [first, last) of the always-on list (patterns of more than two state words).
+__global__ __launch_bounds__(256) void hg_always_on_kernel(HgConfirmArgs a, uint32_t first, uint32_t last) {
   __shared__ uint32_t s_n, s_base;
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
@@ -934,11 +933,6 @@ __global__ __launch_bounds__(256) void hg_always_on_kernel(HgConfirmArgs a, uint
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
   for (uint64_t tile = a.tile_begin + ((static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6); tile < a.tile_end; tile += waves) {
-    if (broken_only) {
-      const uint64_t tile_start = tile << HG_TILE_SHIFT;
-      const uint64_t tile_stop = tile_start + HG_TILE_BYTES < a.nbytes ? tile_start + HG_TILE_BYTES : a.nbytes;
-      if (tile_stop - a.bases[tile].cs <= a.bs1) continue;
-    }
     const uint64_t lo = (tile << HG_TILE_SHIFT) + lane * 256ull;
     uint64_t hi = lo + 256;
     if (hi > a.nbytes) hi = a.nbytes;
@@ -963,8 +957,8 @@ __global__ __launch_bounds__(256) void hg_always_on_kernel(HgConfirmArgs a, uint
 // segment plus that much lead-in, independently of the others; '\n' and NUL reset the automaton (a line is scanned on its
 // own, a NUL ends the scanned bytes), and what the reset cannot know — whether an earlier NUL already ended the line — the
 // line geometry decides when a match is reported (LineHead.blocked).  A SINGLEMATCH pattern can report once per lane and
-// line; the ordering pass keeps the smallest end offset.  Tiles in which a forced break of an over-long line falls
-// (carry-in line start more than buffer_size - 1 bytes before the tile end) go through the scalar routine instead.
+// line; the ordering pass keeps the smallest end offset.  Expressions of long or unbounded match length start at the
+// line's start (the piece's start, past a forced break) instead of a fixed lead-in.
 // Tables: one pattern at a time, staged per wave in LDS like the automaton confirm routines.
 // The scan loop only notes a match (end offset, pattern, newlines of the tile before its last byte) in the block's private
 // list; hg_always_on_finish_kernel locates the lines afterwards, every lane busy.  Keeping the line geometry (and its
@@ -983,12 +977,19 @@ __device__ __forceinline__ void always_on_note(const AlwaysOnCtx &cx, uint32_t p
 
 template <int NW, bool SIMPLE>
 __device__ __forceinline__ void always_on_segment(const AlwaysOnCtx &a, const HgPattern &p, uint32_t pi, const hgdev::lds_u32 *tab, uint64_t lo, uint64_t hi,
-                                                  uint32_t rank_lo) {
+                                                  uint64_t line_start, uint64_t bs1, uint32_t rank_lo) {
   if (lo >= hi) return;
   const hgdev::lds_u32 *reach = tab + CT_REACH, *follow = tab + CT_FOLLOW, *amask = tab + CT_AMASK, *acct = tab + CT_ACC;
   const uint8_t *text = a.text;
-  const uint32_t lead = p.max_len - 1;
-  const uint64_t q = lo > lead ? lo - lead : 0;  // first byte the automaton sees
+  // first byte the automaton sees: a match ending in [lo, hi) starts at most max_len - 1 bytes before lo — or, for long /
+  // unbounded expressions, anywhere from the start of the line that contains lo
+  uint64_t q = line_start;
+  if (p.max_len && p.max_len <= HG_ALWAYS_ON_FAST_MAX_LEN) {
+    const uint32_t lead = p.max_len - 1;
+    q = lo > lead ? lo - lead : 0;
+  } else if (lo - line_start >= bs1) {
+    q = line_start + (lo - line_start) / bs1 * bs1;  // the piece that contains lo (forced breaks, below)
+  }
   const uint64_t base = q & ~15ull;
   // offsets relative to base (all < 16 + 63 + 256 + 1): [first, stop) are consumed; `own` = first offset of the own segment;
   // the byte at `stop` (if inside the text) only lends its context to a match ending there
@@ -1001,6 +1002,19 @@ __device__ __forceinline__ void always_on_segment(const AlwaysOnCtx &a, const Hg
   if (q) {
     const uint32_t before = text[q - 1];
     pc = (before == '\n' || before == 0) ? HG_PC_START : hg_prev_ctx(before);
+  }
+  // forced breaks: a line longer than the scan buffer continues as a new piece every bs1 bytes (hyperscanner.c:199); the
+  // automaton starts afresh there.  next_break: offset (relative to base) of the next one, NO_BREAK until the line is known
+  constexpr uint32_t NO_BREAK = 0xFFFFFFFFu;
+  uint32_t next_break = NO_BREAK;
+  auto break_after = [&](uint64_t piece_start) {  // first break after a piece that starts at piece_start
+    const uint64_t at = piece_start + bs1 - base;
+    return at < 0x7FFFFFFFull ? static_cast<uint32_t>(at) : NO_BREAK;
+  };
+  if (q >= line_start) {  // (else a newline inside the lead-in starts the line whose breaks matter)
+    const uint64_t d = q - line_start, k = d < bs1 ? 0 : d / bs1;
+    next_break = break_after(line_start + k * bs1);
+    if (k && d == k * bs1) pc = HG_PC_START;  // q is itself the first byte of a piece
   }
   uint32_t rank = rank_lo;  // newlines in [tile start, current byte) once the walk is inside the own segment
   bool reported = false;    // SINGLEMATCH: this lane already reported the current line
@@ -1024,15 +1038,28 @@ __device__ __forceinline__ void always_on_segment(const AlwaysOnCtx &a, const Hg
       if (r < first || r > stop) continue;
       const bool beyond = r == stop;  // context only (or the end of the text)
       const uint32_t c = (beyond && text_ends) ? 0u : ((v >> (8 * i)) & 0xFFu);
+      if (r == next_break) {  // the piece ends before this byte: END context for a match ending here, then a fresh start
+        if (!SIMPLE) {
+          uint32_t hit = 0;
+#pragma unroll
+          for (int u = 0; u < NW; u++) hit |= S[u] & acct[(pc * 5 + HG_NC_END) * NW + u];
+          if (hit && r > own && !(single && reported)) always_on_note(a, pi, base + r, rank);
+        }
+#pragma unroll
+        for (int u = 0; u < NW; u++) S[u] = 0;
+        pc = HG_PC_START;
+        reported = false;
+        next_break = break_after(base + r);
+      }
       if (!SIMPLE) {
         // a match can end before this byte; the byte decides the right-hand context (END at a NUL / the end of the text)
         const uint32_t cc = c == 0 ? HG_NC_END : (c == '\n' ? HG_NC_NLFINAL : (hg_is_word(c) ? HG_NC_WORD : HG_NC_OTHER));
         uint32_t hit = 0;
 #pragma unroll
         for (int u = 0; u < NW; u++) hit |= S[u] & acct[(pc * 5 + cc) * NW + u];
-        if (hit && r > own && !(single && reported)) {
-          reported = true;
-          always_on_note(a, pi, base + r, rank);
+        if (hit && !(single && reported)) {
+          reported = true;  // (a match that ends in an earlier segment is that segment's to report; it also settles this line)
+          if (r > own) always_on_note(a, pi, base + r, rank);
         }
       }
       if (beyond) continue;
@@ -1054,9 +1081,9 @@ __device__ __forceinline__ void always_on_segment(const AlwaysOnCtx &a, const Hg
         }
       if (SIMPLE) {
         S[0] = T[0] & rc[i][0];
-        if ((S[0] & acc_all) && r >= own && !(single && reported)) {
-          reported = true;
-          always_on_note(a, pi, base + r + 1, rank);
+        if ((S[0] & acc_all) && !(single && reported)) {
+          reported = true;  // (a match that ends in an earlier segment is that segment's to report; it also settles this line)
+          if (r >= own) always_on_note(a, pi, base + r + 1, rank);
         }
       } else {
         const uint32_t cc = c == '\n' ? HG_NC_NLFINAL : (hg_is_word(c) ? HG_NC_WORD : HG_NC_OTHER);
@@ -1075,6 +1102,7 @@ __device__ __forceinline__ void always_on_segment(const AlwaysOnCtx &a, const Hg
         for (int u = 0; u < NW; u++) S[u] = 0;
         pc = HG_PC_START;
         reported = false;
+        next_break = break_after(base + r + 1);
       } else {
         pc = hg_prev_ctx(c);
       }
@@ -1095,21 +1123,30 @@ __global__ __launch_bounds__(256) void hg_always_on_fast_kernel(HgConfirmArgs a)
   const uint64_t waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
   for (uint64_t tile = a.tile_begin + ((static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6); tile < a.tile_end; tile += waves) {
     const uint64_t tile_start = tile << HG_TILE_SHIFT;
-    const uint64_t tile_stop = tile_start + HG_TILE_BYTES < a.nbytes ? tile_start + HG_TILE_BYTES : a.nbytes;
     const uint64_t lo = tile_start + lane * 256ull < a.nbytes ? tile_start + lane * 256ull : a.nbytes;
     const uint64_t hi = lo + 256 < a.nbytes ? lo + 256 : a.nbytes;
-    // newlines per segment -> rank of the segment start (aligned 16-byte chunks, SWAR)
-    uint32_t cnt = 0;
+    // newlines per segment -> rank of the segment start; last newline of the segment -> line start of the later segments
+    // (aligned 16-byte chunks, SWAR)
+    uint32_t cnt = 0, after_last = 0;  // after_last: offset in the tile just past the segment's last newline, 0 = none
     for (uint64_t chunk = lo; chunk < hi; chunk += 16) {
       const uint4 v = *reinterpret_cast<const uint4 *>(a.text + chunk);
       uint32_t m = hgdev::eq_mask16(v, 0x0a0a0a0au);
       if (hi - chunk < 16) m &= (1u << static_cast<uint32_t>(hi - chunk)) - 1u;
       cnt += __popc(m);
+      if (m) after_last = static_cast<uint32_t>(chunk - tile_start) + (31 - __clz(m)) + 1;
     }
     const uint32_t rank_lo = wave_inclusive_scan(cnt, lane) - cnt;
     const HgTileBase tb = a.bases[tile];
-    const bool plain = tile_stop - tb.cs <= a.bs1;  // no forced break of an over-long line inside this tile (wave-uniform)
-    if (!plain) continue;  // hg_always_on_kernel(broken_only) takes this tile
+    // start of the line that contains lo: past the last newline of the earlier segments, else the carry-in line's start
+    uint32_t prev = after_last;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t u = __shfl_up(prev, o, 64);
+      if (lane >= static_cast<uint32_t>(o) && u > prev) prev = u;
+    }
+    prev = __shfl_up(prev, 1, 64);
+    if (lane == 0) prev = 0;
+    const uint64_t line_start = prev ? tile_start + prev : tb.cs;
     for (uint32_t j = 0; j < a.db.nslow_fast; j++) {  // wave-uniform
       const uint32_t pi = a.db.slow[j];
       const HgPattern &p = a.db.patterns[pi];
@@ -1119,9 +1156,9 @@ __global__ __launch_bounds__(256) void hg_always_on_fast_kernel(HgConfirmArgs a)
       else stage_tables<true>(tab, a.db.pool, p, p.nw, lane);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      if (simple) always_on_segment<1, true>(cx, p, pi, tab, lo, hi, rank_lo);
-      else if (p.nw == 1) always_on_segment<1, false>(cx, p, pi, tab, lo, hi, rank_lo);
-      else always_on_segment<2, false>(cx, p, pi, tab, lo, hi, rank_lo);
+      if (simple) always_on_segment<1, true>(cx, p, pi, tab, lo, hi, line_start, a.bs1, rank_lo);
+      else if (p.nw == 1) always_on_segment<1, false>(cx, p, pi, tab, lo, hi, line_start, a.bs1, rank_lo);
+      else always_on_segment<2, false>(cx, p, pi, tab, lo, hi, line_start, a.bs1, rank_lo);
     }
   }
   __syncthreads();
@@ -1148,7 +1185,12 @@ __global__ __launch_bounds__(256) void hg_always_on_finish_kernel(HgConfirmArgs 
     const uint64_t end = d.pos, pos = end - 1;  // the match's last byte; d.rank = newlines of the tile before it
     hgdev::PieceView pv;
     if (!hgdev::piece_view(a.text, a.nbytes, a.sums, a.bases, a.bs1, pos, d.rank, pos, &pv)) continue;
-    if (!pv.whole) continue;  // cannot happen in a tile without forced breaks
+    if (!pv.whole) {  // a later piece of an over-long line: the NUL rules byte by byte (rare)
+      if (pv.a > pos) continue;
+      bool blocked = false;
+      for (uint64_t i = pv.a; i < pos && !blocked; i++) blocked = a.text[i] == 0;
+      if (blocked) continue;
+    }
     const uint64_t z = a.text[pos] == '\n' ? end : hgdev::scanned_end(a.text, end, pv.limit);
     sink.push(pv.line_no, a.db.patterns[d.pattern].id, static_cast<uint32_t>(end - pv.a), pv.a, static_cast<uint32_t>(z - pv.a), d.pattern);
   }

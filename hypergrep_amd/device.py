@@ -98,7 +98,7 @@ class Database:
         return {n: getattr(out, n) for n, _ in HgDbInfo._fields_}
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:  # (module globals are gone at interpreter shutdown)
             lib().hg_db_release(self._h)
             self._h = None
 
@@ -161,7 +161,7 @@ class Scanner:
         return n
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:  # (module globals are gone at interpreter shutdown)
             lib().hg_scanner_destroy(self._h)
             self._h = None
 

@@ -549,3 +549,35 @@ def test_chunked_pipeline_equals_single_pass(torch_cuda, monkeypatch, mib, chunk
     assert many.stream_launches >= 3
     assert (many.n_hits, many.n_lines) == (one.n_hits, one.n_lines) and one.n_hits > 10000
     assert bool((a == b).all())
+
+
+def test_always_on_patterns_segment_scan(torch_cuda):
+    """Patterns without a long required literal (always-on tier): bounded ones scan 256-byte segments with max_len - 1 bytes
+    of lead-in, unbounded ones from their line's start; tiles with forced breaks or a long carry-in line go to the scalar
+    routine.  Text with lines from empty to 40 KiB, NULs, CRLF, and matches across segment and tile borders."""
+    rng = random.Random(99)
+    pats = ["ab", "x", "foo|bar", "[0-9]+\\.[0-9]+", "a.*z", "\\bGET\\b", "^warn", "end$", "(?i)eRRoR", "q{2,3}", "[^a-z \\n]{3}"]
+    flags = [14, 14, 14, 14, 14, 14, 14, 14, 15, 6, 6]  # the last two report every match end (no SINGLEMATCH)
+    ids = list(range(len(pats)))
+    words = ["ab", "x", "foo", "bar", "12.5", "7.", "a", "z", "GET", "GETS", "warn", "end", "Error", "ERROR", "qq", "qqqq", "A1B2", "", "lorem", "ipsum"]
+    lines = []
+    for i in range(6000):
+        n = rng.choice([0, 1, 3, 8, 20, 20, 60, 300]) if i % 500 else 9000  # every 500th line is ~40 KiB: longer than two tiles
+        toks = [rng.choice(words) for _ in range(n)]
+        line = " ".join(toks)
+        if i % 97 == 0:
+            line = line[: len(line) // 2] + "\0" + line[len(line) // 2:]
+        if i % 131 == 0:
+            line = "\0\0" + line
+        if i % 53 == 0:
+            line += "\r"
+        lines.append(line)
+    data = ("\n".join(lines) + ("\n" if rng.random() < 0.5 else "")).encode()
+    want, nlines = oracle_hits(data, pats, flags, ids)
+    got, stats = gpu_scan_buffer(torch_cuda, data, pats, flags, ids)
+    assert stats.n_lines == nlines
+    assert got == want and len(want) > 20000
+    # forced breaks: a scan buffer shorter than the long lines
+    want2, nlines2 = oracle_hits(data, pats, flags, ids, buffer_size=20000)
+    got2, stats2 = gpu_scan_buffer(torch_cuda, data, pats, flags, ids, buffer_size=20000)
+    assert stats2.n_lines == nlines2 and got2 == want2

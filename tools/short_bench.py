@@ -1,9 +1,10 @@
+"""Throughput of patterns without a long required literal (always-on tier) next to a prefiltered one; GPU box only."""
 import sys, time
 sys.path.insert(0, '/root/repo')
 import torch
 from hypergrep_amd import benchspec, device
 patterns, needles, hpm = benchspec.c3_spec()
-for pats in (["ERROR"], ["foo|bar"], ["status=5[0-9]{2}"], ["ERROR", "WARN", "panic", "fail"]):
+for pats in (["ERROR"], ["foo|bar"], ["status=5[0-9]{2}"], ["ERROR", "WARN", "panic", "fail"], ["[0-9]+\\.[0-9]+"], ["fail.*time"], ["\\bGET\\b"]):
     nbytes = 1 << 30
     text = torch.empty(nbytes + 64, dtype=torch.uint8, device="cuda:0")
     device.synth_device(text.data_ptr(), nbytes, 77, needles, hpm)
