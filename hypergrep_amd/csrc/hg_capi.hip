@@ -67,6 +67,7 @@ int hg_db_info(const hg_database_t *db, hg_db_info_t *info) {
   info->fold_mask = d.fold_mask;
   info->max_state_words = d.max_nw;
   info->table_bytes = static_cast<uint32_t>(d.pool.size() * 4);
+  info->byte_windows = d.dense;
   return HG_OK;
 }
 

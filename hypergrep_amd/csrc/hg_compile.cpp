@@ -15,6 +15,7 @@
 #include <array>
 #include <bitset>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -913,26 +914,37 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
   for (uint32_t fi = 0; fi < db.nreal_factors; fi++) {
     const HgFactor &fct = db.factors[fi];
     Lit l{std::string(reinterpret_cast<const char *>(fct.lit), fct.len), std::string(reinterpret_cast<const char *>(fct.cmask), fct.len)};
-    for (uint32_t res = 0; res < 4; res++) {
-      // One 3-byte window per residue mod 4.  The stream kernel compares the window in its hot path and the 11-byte
-      // neighbourhood [o-4, o+7) in the second level.
+    if (db.dense && fct.len < HG_WINDOW_BYTES) {
+      // a literal one byte short of a window: every value of the byte after it (the stream pass reads zeros past the text)
+      std::vector<uint32_t> seen;
+      for (uint32_t last = 0; last < 256; last++) {
+        uint32_t v = 0;
+        std::memcpy(&v, fct.lit, fct.len);
+        v = ((v | (last << 24)) | fold) & HG_WINDOW_MASK;
+        if (std::find(seen.begin(), seen.end(), v) != seen.end()) continue;  // folding maps two bytes onto one value
+        seen.push_back(v);
+        keyed.push_back({hg_hash_window(v), HgWindow{v, fi << 8}});
+        next16_of.push_back(0);
+      }
+      continue;
+    }
+    // One window per residue mod 4 (the stream pass probes dword-aligned windows) — or, with byte-aligned probing
+    // (db.dense), ONE window per literal at any offset.
+    for (uint32_t res = 0; res < (db.dense ? 1u : 4u); res++) {
+      // The stream kernel compares the window in its hot path and the 12-byte neighbourhood [o-4, o+8) in the second level.
       // With sample statistics: take the offset whose window dword is rarest in the sample.  Without:
       // the offset whose known bytes are the most selective by a static byte-frequency table.
       int best = -1;
       long best_cost = 0;
       int best_sel = -1;
-      for (uint32_t o = res; o + HG_WINDOW_BYTES <= fct.len; o += 4) {
-        uint32_t v = 0, nx = 0;
+      for (uint32_t o = res; o + HG_WINDOW_BYTES <= fct.len; o += db.dense ? 1 : 4) {
+        uint32_t v = 0;
         std::memcpy(&v, fct.lit + o, HG_WINDOW_BYTES);
         v = (v | fold) & HG_WINDOW_MASK;
-        const bool has_next = o + 6 <= fct.len;
-        if (has_next) nx = (static_cast<uint32_t>(fct.lit[o + 4]) | (static_cast<uint32_t>(fct.lit[o + 5]) << 8) | fold) & 0xFFFFu;
         long cost = 0;
         if (stats) {  // the hot path compares the window dword alone: its frequency in the sample is what costs
           auto it = stats->c4.find(v);
           cost = it == stats->c4.end() ? 0 : it->second;
-          (void)nx;
-          (void)has_next;
         }
         int sel = 0;
         for (int j = static_cast<int>(o); j < static_cast<int>(o + HG_WINDOW_BYTES); j++) sel += 11 - byte_commonness(static_cast<unsigned char>(l.bytes[j]));
@@ -944,9 +956,8 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
       uint32_t v = 0;
       std::memcpy(&v, fct.lit + best, HG_WINDOW_BYTES);
       v = (v | fold) & HG_WINDOW_MASK;  // case-insensitive positions hold lower-case letters already; folding maps both cases onto them
-      uint32_t n16 = 0;  // (reserved: hash of the two bytes after the window)
       keyed.push_back({hg_hash_window(v), HgWindow{v, (fi << 8) | static_cast<uint32_t>(best)}});
-      next16_of.push_back(n16);
+      next16_of.push_back(0);
     }
   }
   {  // sort by bucket, carrying next16 along
@@ -1142,6 +1153,10 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
     }
   }
   db.filter_wide = 0;
+  if (!placed && db.dense) {
+    if (err) *err = "too many literal windows for byte-aligned probing";
+    return -5;  // the caller falls back to dword-aligned windows
+  }
   if (!placed) {
     // Wide mode for large pattern sets: every 4-byte slot holds TWO 16-bit fingerprints (cells), each window may sit
     // in either cell of either of its two slots (bucketed cuckoo, usable up to ~85 % of the cells), and the neighbour
@@ -1218,7 +1233,7 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
     return -4;
   }
   auto db = std::make_unique<HgDb>();
-  struct Pending { std::vector<Lit> lits; bool caseless; };
+  struct Pending { std::vector<Lit> lits; bool literal_only = false; };
   std::vector<Pending> covers(n);
   unsigned cur = 0;
   try {
@@ -1313,31 +1328,20 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
       LitSet cover;
       if (info.has_cover) for (auto &l : info.cover) cover.push_back(clip(l));
       dedupe(cover);
-      bool fast = !cover.empty() && min_len(cover) >= HG_FAST_MIN_FACTOR;
-      // a literal containing '\n' before its last byte can never lie inside one line; keep such patterns always-on
-      p.tier = fast ? 0 : 1;
+      covers[cur].lits = cover;
       // literal-only: the expression's language is exactly one literal that fits the factor record, has no NUL
       // or inner newline, and no assertions -> a verified factor occurrence is a match
-      if (fast && info.exact && info.set.size() == 1 && cover.size() == 1 && info.set[0].bytes.size() <= HG_FACTOR_MAX &&
+      if (info.exact && info.set.size() == 1 && cover.size() == 1 && info.set[0].bytes.size() <= HG_FACTOR_MAX &&
           cover[0] == info.set[0] && !has_assert(*root)) {
         const std::string &lb = info.set[0].bytes;
         bool clean = true;
         for (size_t j = 0; j < lb.size(); j++)
           if (lb[j] == 0 || (lb[j] == '\n' && j + 1 < lb.size())) clean = false;
-        p.literal_only = clean ? 1 : 0;
+        covers[cur].literal_only = clean;
       }
       {
         const long ml = max_match_len(*root);
         p.max_len = ml > 0 ? static_cast<uint32_t>(ml) : 0;
-      }
-      if (fast) db->n_confirm_mode[hg_confirm_mode(p)]++;
-      if (fast) {
-        covers[cur].lits = cover;
-        for (auto &l : cover)
-          for (unsigned char m : l.cmask)
-            if (m != 0xFF) db->fold_mask = 0x20202020u;
-      } else {
-        db->slow.push_back(cur);
       }
       db->patterns.push_back(p);
     }
@@ -1351,31 +1355,65 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
     return -2;
   }
 
-  // always-on patterns of at most two state words go first: the segment-parallel kernel takes those
-  {
-    auto fast = [&](uint32_t pi) {
-      const HgPattern &p = db->patterns[pi];
-      return p.nw <= 2;  // bounded or not: an unbounded pattern's lead-in is the start of its line
-    };
-    std::stable_partition(db->slow.begin(), db->slow.end(), fast);
-    db->nslow_fast = static_cast<uint32_t>(std::count_if(db->slow.begin(), db->slow.end(), fast));
-  }
-
-  // factors (needs the final fold mask); windows and filter tables are built from them
-  for (unsigned i = 0; i < n; i++) {
-    for (auto &l : covers[i].lits) {
-      HgFactor fct{};
-      fct.pattern = i;
-      fct.len = static_cast<uint32_t>(l.bytes.size());
-      fct.mode = hg_confirm_mode(db->patterns[i]);
-      std::memcpy(fct.lit, l.bytes.data(), fct.len);
-      std::memcpy(fct.cmask, l.cmask.data(), fct.len);
-      db->factors.push_back(fct);
+  // Tiers.  A pattern whose required literals all have at least `min_factor` bytes is found through the window prefilter
+  // (tier 0), the others run on every line (tier 1).  Dword-aligned windows need HG_FAST_MIN_FACTOR bytes (a window on
+  // every residue mod 4).  When that leaves patterns with shorter literals behind, the stream pass probes a window at
+  // every BYTE offset instead (db.dense: four times the probes, a third of the streaming rate — still several times the
+  // always-on tier), which takes literals down to HG_DENSE_MIN_FACTOR bytes.
+  auto assign = [&](uint32_t min_factor, uint32_t dense) -> int {
+    db->dense = dense;
+    db->slow.clear();
+    db->factors.clear();
+    db->fold_mask = 0;
+    for (uint32_t m = 0; m < HG_CONFIRM_MODES; m++) db->n_confirm_mode[m] = 0;
+    for (unsigned i = 0; i < n; i++) {
+      HgPattern &p = db->patterns[i];
+      const LitSet &cover = covers[i].lits;
+      const bool fast = !cover.empty() && min_len(cover) >= min_factor;
+      p.tier = fast ? 0 : 1;
+      p.literal_only = (fast && covers[i].literal_only) ? 1 : 0;
+      if (fast) {
+        db->n_confirm_mode[hg_confirm_mode(p)]++;
+        for (auto &l : cover)
+          for (unsigned char m : l.cmask)
+            if (m != 0xFF) db->fold_mask = 0x20202020u;
+      } else {
+        db->slow.push_back(i);
+      }
     }
+    // always-on patterns of at most two state words go first: the segment-parallel kernel takes those
+    auto two_words = [&](uint32_t pi) { return db->patterns[pi].nw <= 2; };  // bounded or not: an unbounded pattern's lead-in is the start of its line
+    std::stable_partition(db->slow.begin(), db->slow.end(), two_words);
+    db->nslow_fast = static_cast<uint32_t>(std::count_if(db->slow.begin(), db->slow.end(), two_words));
+    // factors (needs the final fold mask); windows and filter tables are built from them
+    for (unsigned i = 0; i < n; i++) {
+      if (db->patterns[i].tier != 0) continue;
+      for (auto &l : covers[i].lits) {
+        HgFactor fct{};
+        fct.pattern = i;
+        fct.len = static_cast<uint32_t>(l.bytes.size());
+        fct.mode = hg_confirm_mode(db->patterns[i]);
+        std::memcpy(fct.lit, l.bytes.data(), fct.len);
+        std::memcpy(fct.cmask, l.cmask.data(), fct.len);
+        db->factors.push_back(fct);
+      }
+    }
+    db->nreal_factors = static_cast<uint32_t>(db->factors.size());
+    if (db->factors.empty()) db->factors.push_back(HgFactor{});  // keep device arrays non-empty
+    return build_filter(*db, nullptr, err);
+  };
+  size_t shortest = SIZE_MAX;  // shortest required literal among the patterns dword-aligned windows leave behind
+  for (unsigned i = 0; i < n; i++) {
+    const size_t m = covers[i].lits.empty() ? 0 : min_len(covers[i].lits);
+    if (m >= HG_DENSE_MIN_FACTOR && m < HG_FAST_MIN_FACTOR) shortest = std::min(shortest, m);
   }
-  db->nreal_factors = static_cast<uint32_t>(db->factors.size());
-  if (db->factors.empty()) db->factors.push_back(HgFactor{});  // keep device arrays non-empty
-  if (build_filter(*db, nullptr, err) != 0) {
+  int rc = -5;
+  if (shortest != SIZE_MAX && !std::getenv("HG_NO_BYTE_WINDOWS")) {
+    rc = assign(static_cast<uint32_t>(shortest), 1);
+    if (rc == -5 && shortest < HG_WINDOW_BYTES) rc = assign(HG_WINDOW_BYTES, 1);  // without the enumerated short literals
+  }
+  if (rc == -5) rc = assign(HG_FAST_MIN_FACTOR, 0);
+  if (rc != 0) {
     if (bad_index) *bad_index = -1;
     return -4;
   }
@@ -1387,7 +1425,7 @@ int hgc_tune(HgDb *db, const uint8_t *sample, size_t nbytes, std::string *err) {
   if (!db || (!sample && nbytes)) return -1;
   SampleStats st;
   const uint32_t fold = db->fold_mask;
-  for (size_t p = 0; p + 4 <= nbytes; p += 4) {
+  for (size_t p = 0; p + 4 <= nbytes; p += db->dense ? 1 : 4) {
     uint32_t w, nx = 0;
     std::memcpy(&w, sample + p, 4);
     if (p + 8 <= nbytes) std::memcpy(&nx, sample + p + 4, 4);

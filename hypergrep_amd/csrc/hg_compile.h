@@ -21,6 +21,7 @@ struct HgDb {
   std::vector<uint32_t> filter;      // 1 << filter_log2 slots holding hash C of the owning window (staged in LDS by the stream kernel)
   uint32_t filter_log2 = HG_FILTER_MIN_LOG2;
   uint32_t filter_wide = 0;          // 1: two 16-bit fingerprints per slot, no neighbour conditions (large pattern sets)
+  uint32_t dense = 0;                // 1: the stream pass probes a window at every byte offset, one window per literal (sets with short literals)
   uint32_t weights_a = HG_SLOT_WEIGHT_CHOICES[0][0], weights_b = HG_SLOT_WEIGHT_CHOICES[0][1];
   std::vector<HgSlotInfo> ext;       // per filter slot: the window values in it and their neighbour-dword conditions (second-level check)
   std::vector<uint32_t> slow;        // indices of tier-1 (always-on) patterns, the nslow_fast bounded ones with <= 2 state words first

@@ -135,7 +135,8 @@ __device__ __forceinline__ LineHead line_head(const uint8_t *text, uint64_t tile
         h.a = chunk + (__ffs(data) - 1);
       }
       if (nul) nul_above = true;
-      return stop || h.blocked;
+      // (a blocked walk may only end early when the line start is known without it: the caller needs s for the piece index)
+      return stop || (h.blocked && rank == 0);
     });
   }
   return h;

@@ -33,6 +33,7 @@ constexpr uint32_t HG_FACTOR_MAX = 32;   // bytes of a required literal kept for
 constexpr uint32_t HG_WINDOW_BYTES = 4;
 constexpr uint32_t HG_WINDOW_MASK = HG_WINDOW_BYTES == 4 ? 0xFFFFFFFFu : 0x00FFFFFFu;
 constexpr uint32_t HG_FAST_MIN_FACTOR = HG_WINDOW_BYTES + 3;  // a window on every residue mod 4
+constexpr uint32_t HG_DENSE_MIN_FACTOR = HG_WINDOW_BYTES - 1;  // byte-aligned probing: one window anywhere; one byte short: the byte after the literal enumerated
 constexpr uint32_t HG_HASH_BITS = 18;       // v_dot4_u32_u8 of four bytes with weights < 256 fits 18 bits
 // Byte-weighted sums of the (case-folded) window dword, one v_dot4_u32_u8 each:
 //   hash C  -> bucket index of the window table in HBM, and (low 16 bits) the fingerprint

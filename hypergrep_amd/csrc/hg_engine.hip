@@ -13,7 +13,7 @@
 
 // kernels (hg_kernels.hip)
 void hg_launch_stream(const HgStreamArgs &a, uint32_t grid, hipStream_t stream);
-int hg_stream_blocks_per_cu(uint32_t filter_log2, uint32_t filter_wide);
+int hg_stream_blocks_per_cu(uint32_t filter_log2, uint32_t filter_wide, uint32_t dense);
 __global__ void hg_tile_reduce_kernel(const HgTileSum *sums, uint64_t tile_begin, uint64_t tile_end, uint64_t bs1, HgTileElem *agg);
 __global__ void hg_tile_spine_kernel(const HgTileElem *agg, uint32_t nblocks, uint64_t bs1, HgTileBase *block_base, HgTileBase *state);
 __global__ void hg_tile_apply_kernel(const HgTileSum *sums, uint64_t tile_begin, uint64_t tile_end, uint64_t bs1, const HgTileBase *block_base,
@@ -243,13 +243,39 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
     if (!block_mode && v >= TS_BLOCK_TILES) chunk_tiles = std::max<uint64_t>(v / TS_BLOCK_TILES * TS_BLOCK_TILES, (ntiles + kMaxChunks - 1) / kMaxChunks / TS_BLOCK_TILES * TS_BLOCK_TILES + TS_BLOCK_TILES);
   }
   nchunks = ntiles ? static_cast<uint32_t>((ntiles + chunk_tiles - 1) / chunk_tiles) : 1;
+  std::vector<uint64_t> cut(nchunks + 1);  // chunk c = tiles [cut[c], cut[c + 1])
+  for (uint32_t c = 0; c <= nchunks; c++) cut[c] = std::min<uint64_t>(static_cast<uint64_t>(c) * chunk_tiles, ntiles);
+  if (const char *env = std::getenv("HG_CHUNK_WEIGHTS")) {  // experiment: relative chunk sizes, e.g. "10,10,8,4"
+    std::vector<double> w;
+    for (const char *q = env; *q;) {
+      char *e = nullptr;
+      const double v = std::strtod(q, &e);
+      if (e == q) break;
+      if (v > 0) w.push_back(v);
+      q = *e ? e + 1 : e;
+    }
+    if (!block_mode && w.size() >= 2 && w.size() <= static_cast<size_t>(kMaxChunks) && ntiles >= w.size() * TS_BLOCK_TILES * 2) {
+      double total = 0, run = 0;
+      for (double v : w) total += v;
+      nchunks = static_cast<uint32_t>(w.size());
+      cut.assign(nchunks + 1, 0);
+      chunk_tiles = 0;
+      for (uint32_t c = 0; c < nchunks; c++) {
+        run += w[c];
+        uint64_t end = c + 1 == nchunks ? ntiles : static_cast<uint64_t>(static_cast<double>(ntiles) * run / total) / TS_BLOCK_TILES * TS_BLOCK_TILES;
+        end = std::min<uint64_t>(std::max<uint64_t>(end, cut[c] + TS_BLOCK_TILES), ntiles);
+        cut[c + 1] = end;
+        chunk_tiles = std::max<uint64_t>(chunk_tiles, end - cut[c]);
+      }
+    }
+  }
   const bool piped = nchunks > 1;
 
   uint32_t wgs = 1, confirm_blocks = 1, always_blocks = 1;
   out->ms_stream = 0;
   out->stream_launches = ntiles ? nchunks : 0;
   if (ntiles) {
-    if (stream_wgs_per_cu_ == 0) stream_wgs_per_cu_ = hg_stream_blocks_per_cu(db_->filter_log2, db_->filter_wide);
+    if (stream_wgs_per_cu_ == 0) stream_wgs_per_cu_ = hg_stream_blocks_per_cu(db_->filter_log2, db_->filter_wide, db_->dense);
     uint32_t per_cu = piped ? std::max(1, stream_wgs_per_cu_ - 1) : stream_wgs_per_cu_;
     if (const char *env = std::getenv("HG_STREAM_WGS_PER_CU")) {  // tuning knob: resident stream workgroups per CU
       const long v = std::strtol(env, nullptr, 10);
@@ -272,7 +298,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       HG_TRY(hipStreamWaitEvent(side, ev_side_done_[kMaxChunks - 1], 0), "stream wait");
     }
     for (uint32_t c = 0; c < nchunks; c++) {
-      const uint64_t t0 = static_cast<uint64_t>(c) * chunk_tiles, t1 = std::min<uint64_t>(t0 + chunk_tiles, ntiles);
+      const uint64_t t0 = cut[c], t1 = cut[c + 1];
       const uint32_t wgs_c = c == 0 ? wgs_alone : wgs_shared;
       const uint32_t set = piped ? (c & 1u) : 0u;
       HgCand *cands = set ? d_cands2_ : d_cands_;
@@ -290,6 +316,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       sa.weights_a = db_->weights_a;
       sa.weights_b = db_->weights_b;
       sa.filter_wide = db_->filter_wide;
+      sa.dense = db_->dense;
       // every workgroup streams its own consecutive range of tiles: same HBM rate as dealing tiles round-robin (measured),
       // and the verify / confirm passes then find neighbouring lines in neighbouring lanes (confirm 1.8 -> 1.5 ms per 32 GiB)
       sa.span = static_cast<uint32_t>(((t1 - t0 + wgs_c - 1) / wgs_c + STREAM_WG_WAVES - 1) / STREAM_WG_WAVES * STREAM_WG_WAVES);

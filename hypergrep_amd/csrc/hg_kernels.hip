@@ -61,8 +61,9 @@ constexpr uint32_t queue_cap(int) { return 128u; }
 // dwords per entry: {chunk | rank << 10, tile} and, while LDS has room (filters up to 16 KiB, three workgroups per CU), also
 // {left, right, the chunk's four dwords} so that the drain does not read the text again (measured: re-reading costs ~15 % extra
 // HBM fetches on the round-1 workload, the streamed tiles have left the L2 by then)
-constexpr bool queue_stash(int log2) { return log2 <= 12; }
-constexpr uint32_t queue_entry_dw(int log2) { return queue_stash(log2) ? 8u : 2u; }
+// (byte-aligned probing re-reads the text: its drain wants up to 28 bytes around the chunk)
+constexpr bool queue_stash(int log2, bool dense) { return log2 <= 12 && !dense; }
+constexpr uint32_t queue_entry_dw(int log2, bool dense) { return queue_stash(log2, dense) ? 8u : 2u; }
 
 template <int LOG2, bool WIDE>
 struct Probe {
@@ -96,6 +97,45 @@ struct Probe {
     return (m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u) | (m3 ? 8u : 0u);  // bit k: window k matched
   }
 };
+
+// Byte-aligned probing (pattern sets with required literals shorter than HG_FAST_MIN_FACTOR, db.dense): every byte of the
+// lane's 16 is the start of a window, `nxt` = the dword after the chunk.  One window per literal instead of one per
+// residue; four times the probes of the dword-aligned filter.
+template <int LOG2>
+struct ProbeBytes {
+  static constexpr uint32_t BYTE_MASK = ((1u << LOG2) - 1u) << 2;
+  // ANY_ONLY: non-zero iff any of the 16 windows matched; else bit k = the window that starts at byte k matched
+  template <bool ANY_ONLY>
+  __device__ __forceinline__ static uint32_t probe16(const lds_u32 *filter, uint32_t fold, uint32_t wa, uint4 v, uint32_t nxt) {
+    const uint32_t d[5] = {v.x | fold, v.y | fold, v.z | fold, v.w | fold, nxt | fold};
+    uint32_t bits = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      uint32_t w[4], t[4];
+      w[0] = d[j];
+#pragma unroll
+      for (int k = 1; k < 4; k++) w[k] = __builtin_amdgcn_alignbyte(d[j + 1], d[j], k);
+#pragma unroll
+      for (int k = 0; k < 4; k++) t[k] = Probe<LOG2, false>::at(filter, hg_dot4(w[k], wa) & BYTE_MASK);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const bool m = hg_slot_match(t[k], hg_dot4(w[k], HG_HASH_WEIGHTS));
+        if (ANY_ONLY) bits |= m ? 1u : 0u;
+        else bits |= m ? (1u << (j * 4 + k)) : 0u;
+      }
+    }
+    return bits;
+  }
+};
+
+// Dword at byte offset `at` (a multiple of 4) of the text, bytes past the end of the text zeroed.
+__device__ __forceinline__ uint32_t load_dword_checked(const uint4 *__restrict__ text16, uint64_t nbytes, uint64_t at) {
+  if (at >= nbytes) return 0u;
+  uint32_t v = reinterpret_cast<const uint32_t *>(text16)[at >> 2];
+  const uint64_t rest = nbytes - at;
+  if (rest < 4) v &= (1u << (rest * 8)) - 1u;
+  return v;
+}
 
 // Everything the out-of-line drain routine needs besides the per-tile state (wave-uniform; lives in SGPRs).
 struct StreamCtx {
@@ -131,26 +171,93 @@ __device__ __forceinline__ uint4 load_chunk_checked(const uint4 *__restrict__ te
   return v;
 }
 
+typedef uint32_t __attribute__((aligned(1))) hg_u32_unaligned;
+// The window that starts at byte k (0..15) of the chunk `cur`, `nxt` = the dword after the chunk.
+__device__ __forceinline__ uint32_t dense_window(uint4 cur, uint32_t nxt, uint32_t k) {
+  const uint32_t j = k >> 2;
+  const uint32_t lo = j == 0 ? cur.x : (j == 1 ? cur.y : (j == 2 ? cur.z : cur.w));
+  const uint32_t hi = j == 0 ? cur.y : (j == 1 ? cur.z : (j == 2 ? cur.w : nxt));
+  return static_cast<uint32_t>(((static_cast<uint64_t>(hi) << 32) | lo) >> (8u * (k & 3u)));
+}
+
 // Drain of one batch of the wave's queue (the rare half of the stream pass, out of line).  The hot loop only records
 // WHICH 16-byte chunks had a first-level match (tile, chunk inside the tile, newlines of the tile before the chunk); here
 // one lane takes one such chunk, re-reads it and its two neighbouring dwords (L2-resident: the tile was streamed moments
 // ago), repeats the first level per window, applies the second level (the slot's neighbour conditions) and appends the
 // survivors to the workgroup's candidate segment.  The queue outlives tiles, so batches are full (64 entries) except the
 // last one of the kernel.
-template <int LOG2, bool WIDE>
+template <int LOG2, bool WIDE, bool DENSE>
 __device__ __noinline__ void drain_batch(const StreamCtx cx, uint32_t first, uint32_t n, uint32_t lane) {
   const bool active = lane < n;
   uint32_t hits = 0, rank = 0;
   uint64_t g = 0;
   uint4 cur = make_uint4(0, 0, 0, 0);
+  if constexpr (DENSE) {
+    // byte-aligned windows: the chunk and the dword after it are read again (L2), the 16 windows probed one by one, the
+    // neighbour conditions taken from the text itself
+    uint32_t nxt = 0;
+    if (active) {
+      const lds_u32 *e = cx.queue + (first + lane) * queue_entry_dw(LOG2, DENSE);
+      const uint32_t e_lo = e[0], e_hi = e[1];
+      g = static_cast<uint64_t>(e_hi) * (HG_TILE_BYTES / 16) + (e_lo & 1023u);
+      rank = e_lo >> 10;
+      cur = load_chunk_checked(cx.text16, cx.nbytes, g);
+      nxt = load_dword_checked(cx.text16, cx.nbytes, (g + 1) << 4);
+      const uint32_t l1 = ProbeBytes<LOG2>::template probe16<false>(cx.filter, cx.fold, cx.wa, cur, nxt);
+      constexpr uint32_t BYTE_MASK = ((1u << LOG2) - 1u) << 2;
+      const uint8_t *text = reinterpret_cast<const uint8_t *>(cx.text16);
+      for (uint32_t todo = l1; todo; todo &= todo - 1) {
+        const uint32_t k = __ffs(todo) - 1;
+        const uint64_t pos = (g << 4) + k;
+        const uint32_t wk = dense_window(cur, nxt, k);
+        // the four bytes before / after the window, zero outside the text
+        uint32_t prev = 0, next = 0;
+        if (pos >= 4 && pos + 8 <= cx.nbytes) {
+          prev = *reinterpret_cast<const hg_u32_unaligned *>(text + pos - 4);
+          next = *reinterpret_cast<const hg_u32_unaligned *>(text + pos + 4);
+        } else {
+          for (uint32_t b = 0; b < 4; b++) {
+            if (pos + b >= 4) prev |= static_cast<uint32_t>(text[pos + b - 4]) << (8 * b);
+            if (pos + 4 + b < cx.nbytes) next |= static_cast<uint32_t>(text[pos + 4 + b]) << (8 * b);
+          }
+        }
+        const uint32_t f = wk | cx.fold;
+        const HgSlotInfo info = cx.ext[(hg_dot4(f, cx.wa) & BYTE_MASK) >> 2];
+        if (hg_slot_pass(info, f, prev | cx.fold, next | cx.fold, 0xFFFFFFFFu, 0xFFFFFFFFu)) hits |= 1u << k;
+      }
+    }
+    const uint32_t cnt = __popc(hits);
+    if (!__builtin_amdgcn_ballot_w64(cnt != 0)) return;
+    const uint32_t incl = wave_inclusive_scan(cnt, lane);
+    const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+    uint32_t base = 0;
+    if (lane == 0) base = __hip_atomic_fetch_add(cx.cand_count, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    base = __builtin_amdgcn_readfirstlane(base);
+    uint32_t s = base + incl - cnt;
+    // newline bytes of the chunk: bit b set iff byte b is '\n'
+    uint32_t nl = 0;
+    {
+      const uint32_t words[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t m = ~not_newline_bits(words[j]);  // bit 7 of each newline byte
+        nl |= (((m >> 7) & 1u) | ((m >> 14) & 2u) | ((m >> 21) & 4u) | ((m >> 28) & 8u)) << (4 * j);
+      }
+    }
+    for (uint32_t todo = hits; todo; todo &= todo - 1, s++) {
+      const uint32_t k = __ffs(todo) - 1;
+      if (s < cx.seg_cap) cx.seg[s] = HgCand{(g << 4) + k, dense_window(cur, nxt, k), rank + __popc(nl & ((1u << k) - 1u))};
+    }
+    return;
+  }
   if (active) {
-    const lds_u32 *e = cx.queue + (first + lane) * queue_entry_dw(LOG2);
+    const lds_u32 *e = cx.queue + (first + lane) * queue_entry_dw(LOG2, DENSE);
     const uint32_t e_lo = e[0], e_hi = e[1];
     g = static_cast<uint64_t>(e_hi) * (HG_TILE_BYTES / 16) + (e_lo & 1023u);
     rank = e_lo >> 10;
     uint32_t left = 0, right = 0;
     bool have_left = (e_lo & 63u) != 0, have_right = (e_lo & 63u) != 63u;  // stashed neighbours come from the adjacent lanes of the 1 KiB row
-    if (queue_stash(LOG2)) {
+    if (queue_stash(LOG2, DENSE)) {
       left = e[2];
       right = e[3];
       cur = make_uint4(e[4], e[5], e[6], e[7]);
@@ -217,7 +324,7 @@ __device__ __noinline__ void drain_batch(const StreamCtx cx, uint32_t first, uin
 
 // One tile.  FULL: the tile lies entirely inside the text (no bounds checks on the hot path).
 // qn: entries in the wave's queue (wave-uniform, carried from tile to tile).
-template <int LOG2, bool WIDE, bool FULL, int DEPTH>
+template <int LOG2, bool WIDE, bool DENSE, bool FULL, int DEPTH>
 __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, HgTileSum *__restrict__ sums, uint32_t lane, uint32_t &qn) {
   const uint4 *__restrict__ text16 = cx.text16;
   const uint64_t nbytes = cx.nbytes;
@@ -233,7 +340,13 @@ __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, 
   uint32_t first_it = HG_NONE32, last_it = 0;  // wave-uniform: iterations holding the first / last newline
   uint32_t first_lane = 0, last_lane = 0;
 
-  auto body = [&](int it, uint4 cur) {
+  // byte-aligned probing: the dword after the lane's chunk is the next lane's first; the row's last lane reads it
+  auto load_after = [&](int it) -> uint32_t {
+    if (!DENSE || lane != 63u) return 0u;
+    return load_dword_checked(text16, nbytes, (chunk0 + static_cast<uint64_t>(it) * 64u + 1u) << 4);
+  };
+
+  auto body = [&](int it, uint4 cur, uint32_t after) {
     // exact newline count of this lane's 16 bytes: 128 - popcount of the "not a newline" bits
     uint32_t notnl = __popc(not_newline_bits(cur.x));
     notnl += __popc(not_newline_bits(cur.y));
@@ -248,7 +361,13 @@ __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, 
 #if defined(HG_ABLATE) && HG_ABLATE == 1  // profiling aid: no window filter (results are wrong)
     const bool any = (cur.x ^ cur.y ^ cur.z ^ cur.w) == 0x12345678u;
 #else
-    const bool any = Probe<LOG2, WIDE>::template probe4<true>(cx.filter, cx.fold, cx.wa, cx.wb, cur) != 0;
+    bool any;
+    if constexpr (DENSE) {
+      const uint32_t nxt = __builtin_amdgcn_update_dpp(after, cur.x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);  // lane 63 keeps `after`
+      any = ProbeBytes<LOG2>::template probe16<true>(cx.filter, cx.fold, cx.wa, cur, nxt) != 0;
+    } else {
+      any = Probe<LOG2, WIDE>::template probe4<true>(cx.filter, cx.fold, cx.wa, cx.wb, cur) != 0;
+    }
 #endif
 
     const uint64_t nlm = __builtin_amdgcn_ballot_w64(c != 0);
@@ -279,10 +398,10 @@ __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, 
       const uint32_t right = __builtin_amdgcn_update_dpp(0u, cur.x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
       if (any) {
         const uint32_t idx = qn + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(am >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(am), 0u));
-        lds_u32 *e = cx.queue + idx * queue_entry_dw(LOG2);
+        lds_u32 *e = cx.queue + idx * queue_entry_dw(LOG2, DENSE);
         e[0] = (static_cast<uint32_t>(it) * 64u + lane) | (before << 10);
         e[1] = static_cast<uint32_t>(tile);
-        if (queue_stash(LOG2)) {
+        if (queue_stash(LOG2, DENSE)) {
           e[2] = left;
           e[3] = right;
           e[4] = cur.x;
@@ -295,7 +414,7 @@ __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, 
       if (qn >= queue_cap(LOG2) - 64u) {
         const uint32_t n = qn < 64u ? qn : 64u;
         qn -= n;
-        drain_batch<LOG2, WIDE>(cx, qn, n, lane);
+        drain_batch<LOG2, WIDE, DENSE>(cx, qn, n, lane);
       }
     }
     seen += total;
@@ -304,17 +423,19 @@ __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, 
   // DEPTH: 16-byte loads in flight per lane
   if constexpr (FULL) {
     uint4 buf[DEPTH];
+    uint32_t abuf[DEPTH];
 #pragma unroll
-    for (int d = 0; d < DEPTH; d++) buf[d] = load_chunk(d);
+    for (int d = 0; d < DEPTH; d++) { buf[d] = load_chunk(d); abuf[d] = load_after(d); }
 #pragma unroll
     for (int it = 0; it < ITERS; it++) {
       const uint4 cur = buf[it % DEPTH];
-      if (it + DEPTH < ITERS) buf[it % DEPTH] = load_chunk(it + DEPTH);
-      body(it, cur);
+      const uint32_t after = abuf[it % DEPTH];
+      if (it + DEPTH < ITERS) { buf[it % DEPTH] = load_chunk(it + DEPTH); abuf[it % DEPTH] = load_after(it + DEPTH); }
+      body(it, cur, after);
     }
   } else {
 #pragma unroll 1
-    for (int it = 0; it < ITERS; it++) body(it, load_chunk(it));
+    for (int it = 0; it < ITERS; it++) body(it, load_chunk(it), load_after(it));
   }
 
   // tile summary: exact offsets of the first / last newline (re-read two 16-byte chunks, L2-resident)
@@ -352,7 +473,7 @@ __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, 
 #endif
 // DEPTH: 16-byte loads in flight per lane.  Measured: with three workgroups resident per CU one is best (more thrashes), with
 // two (next to the side passes of the chunked pipeline) three.
-template <int LOG2, bool WIDE, int DEPTH>
+template <int LOG2, bool WIDE, bool DENSE, int DEPTH>
 __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_STREAM_WAVES, 8))) void hg_stream_kernel(const uint4 *__restrict__ text16, uint64_t nbytes, uint64_t tile_begin, uint64_t tile_end,
                                                                   const uint4 *__restrict__ filter16, const uint4 *__restrict__ ext16,
                                                                   uint32_t fold, uint32_t wa, uint32_t wb, HgTileSum *__restrict__ sums,
@@ -360,7 +481,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_S
                                                                   uint32_t *__restrict__ seg_count, uint32_t *__restrict__ counters, uint32_t span) {
   // LDS, one block so that the filter starts at offset 0 (its byte offsets then fold into the ds_read instructions):
   //   window hash slots (4 B each) | per-wave chunk queues | candidate counter
-  constexpr uint32_t FILTER_U4 = (4u << LOG2) / 16, QUEUE_U4 = WG_WAVES * queue_cap(LOG2) * queue_entry_dw(LOG2) * 4 / 16;
+  constexpr uint32_t FILTER_U4 = (4u << LOG2) / 16, QUEUE_U4 = WG_WAVES * queue_cap(LOG2) * queue_entry_dw(LOG2, DENSE) * 4 / 16;
   __shared__ uint4 s_mem[FILTER_U4 + QUEUE_U4 + 1];
   {
     for (uint32_t i = threadIdx.x; i < FILTER_U4; i += WG_THREADS) s_mem[i] = filter16[i];
@@ -373,7 +494,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_S
   cx.text16 = text16;
   cx.nbytes = nbytes;
   cx.filter = (const lds_u32 *)(&s_mem[0]);
-  cx.queue = (lds_u32 *)(&s_mem[FILTER_U4]) + wave * queue_cap(LOG2) * queue_entry_dw(LOG2);
+  cx.queue = (lds_u32 *)(&s_mem[FILTER_U4]) + wave * queue_cap(LOG2) * queue_entry_dw(LOG2, DENSE);
   cx.cand_count = (lds_u32 *)(&s_mem[FILTER_U4 + QUEUE_U4]);
   cx.ext = reinterpret_cast<const HgSlotInfo *>(ext16);
   cx.seg = cands + static_cast<uint64_t>(blockIdx.x) * seg_cap;  // this workgroup's private output segment
@@ -395,10 +516,10 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_S
   }
   uint32_t qn = 0;
   for (uint64_t tile = tile_first; tile < tile_last; tile += tile_stride) {
-    if (tile < full_tiles) stream_tile<LOG2, WIDE, true, DEPTH>(cx, tile, sums, lane, qn);
-    else stream_tile<LOG2, WIDE, false, DEPTH>(cx, tile, sums, lane, qn);
+    if (tile < full_tiles) stream_tile<LOG2, WIDE, DENSE, true, DEPTH>(cx, tile, sums, lane, qn);
+    else stream_tile<LOG2, WIDE, DENSE, false, DEPTH>(cx, tile, sums, lane, qn);
   }
-  if (qn) drain_batch<LOG2, WIDE>(cx, 0u, qn, lane);
+  if (qn) drain_batch<LOG2, WIDE, DENSE>(cx, 0u, qn, lane);
   __syncthreads();
   if (threadIdx.x == 0) {
     const uint32_t n = *cx.cand_count;
@@ -410,54 +531,74 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_S
 
 // Host-side launcher: picks the instantiation for the database's filter size / mode.
 namespace {
-template <int L, bool W, int D>
+template <int L, bool W, bool B, int D>
 void launch_depth(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
   const uint4 *t = reinterpret_cast<const uint4 *>(a.text);
   const uint4 *f = reinterpret_cast<const uint4 *>(a.filter);
   const uint4 *x = reinterpret_cast<const uint4 *>(a.ext);
-  hipLaunchKernelGGL((hg_stream_kernel<L, W, D>), dim3(grid), dim3(WG_THREADS), 0, stream, t, a.nbytes, a.tile_begin, a.tile_end, f, x, a.db.fold_mask,
+  hipLaunchKernelGGL((hg_stream_kernel<L, W, B, D>), dim3(grid), dim3(WG_THREADS), 0, stream, t, a.nbytes, a.tile_begin, a.tile_end, f, x, a.db.fold_mask,
                      a.weights_a, a.weights_b, a.sums, a.cands, a.cand_seg_cap, a.seg_count, a.counters, a.span);
 }
-template <int L, bool W>
+template <int L, bool W, bool B>
 void launch_one(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
   // filters up to 16 KiB leave room for three workgroups per CU: a launch that has the chip to itself prefetches one chunk ahead
-  if (!W && L <= 12 && a.alone) launch_depth<L, W, (!W && L <= 12) ? 1 : 3>(a, grid, stream);
-  else launch_depth<L, W, 3>(a, grid, stream);
+  if (!W && !B && L <= 12 && a.alone) launch_depth<L, W, B, (!W && !B && L <= 12) ? 1 : 3>(a, grid, stream);
+  else launch_depth<L, W, B, 3>(a, grid, stream);
 }
-template <int L, bool W>
+template <int L, bool W, bool B>
 int blocks_one() {
   int n = 0;
-  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (hg_stream_kernel<L, W, 3>), WG_THREADS, 0);
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (hg_stream_kernel<L, W, B, 3>), WG_THREADS, 0);
   return n > 0 ? n : 1;
 }
 }  // namespace
 void hg_launch_stream(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
   if (a.filter_wide) {
     switch (a.filter_log2) {
-      case 13: launch_one<13, true>(a, grid, stream); break;
-      case 14: launch_one<14, true>(a, grid, stream); break;
-      case 15: launch_one<15, true>(a, grid, stream); break;
+      case 13: launch_one<13, true, false>(a, grid, stream); break;
+      case 14: launch_one<14, true, false>(a, grid, stream); break;
+      case 15: launch_one<15, true, false>(a, grid, stream); break;
+      default: break;
+    }
+    return;
+  }
+  if (a.dense) {  // byte-aligned probing
+    switch (a.filter_log2) {
+      case 11: launch_one<11, false, true>(a, grid, stream); break;
+      case 12: launch_one<12, false, true>(a, grid, stream); break;
+      case 13: launch_one<13, false, true>(a, grid, stream); break;
+      case 14: launch_one<14, false, true>(a, grid, stream); break;
+      case 15: launch_one<15, false, true>(a, grid, stream); break;
       default: break;
     }
     return;
   }
   switch (a.filter_log2) {
-    case 11: launch_one<11, false>(a, grid, stream); break;
-    case 12: launch_one<12, false>(a, grid, stream); break;
-    case 13: launch_one<13, false>(a, grid, stream); break;
-    case 14: launch_one<14, false>(a, grid, stream); break;
-    case 15: launch_one<15, false>(a, grid, stream); break;
+    case 11: launch_one<11, false, false>(a, grid, stream); break;
+    case 12: launch_one<12, false, false>(a, grid, stream); break;
+    case 13: launch_one<13, false, false>(a, grid, stream); break;
+    case 14: launch_one<14, false, false>(a, grid, stream); break;
+    case 15: launch_one<15, false, false>(a, grid, stream); break;
     default: break;
   }
 }
-int hg_stream_blocks_per_cu(uint32_t filter_log2, uint32_t filter_wide) {
-  if (filter_wide) return filter_log2 == 13 ? blocks_one<13, true>() : (filter_log2 == 14 ? blocks_one<14, true>() : blocks_one<15, true>());
+int hg_stream_blocks_per_cu(uint32_t filter_log2, uint32_t filter_wide, uint32_t dense) {
+  if (filter_wide) return filter_log2 == 13 ? blocks_one<13, true, false>() : (filter_log2 == 14 ? blocks_one<14, true, false>() : blocks_one<15, true, false>());
+  if (dense) {
+    switch (filter_log2) {
+      case 11: return blocks_one<11, false, true>();
+      case 12: return blocks_one<12, false, true>();
+      case 13: return blocks_one<13, false, true>();
+      case 14: return blocks_one<14, false, true>();
+      default: return blocks_one<15, false, true>();
+    }
+  }
   switch (filter_log2) {
-    case 11: return blocks_one<11, false>();
-    case 12: return blocks_one<12, false>();
-    case 13: return blocks_one<13, false>();
-    case 14: return blocks_one<14, false>();
-    default: return blocks_one<15, false>();
+    case 11: return blocks_one<11, false, false>();
+    case 12: return blocks_one<12, false, false>();
+    case 13: return blocks_one<13, false, false>();
+    case 14: return blocks_one<14, false, false>();
+    default: return blocks_one<15, false, false>();
   }
 }
 

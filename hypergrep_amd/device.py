@@ -31,7 +31,7 @@ class HgScanResult(ctypes.Structure):
 
 class HgDbInfo(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint32) for n in ("n_patterns", "n_literal_anchored", "n_always_on", "n_factors", "n_windows",
-                                               "fold_mask", "max_state_words", "table_bytes")]
+                                               "fold_mask", "max_state_words", "table_bytes", "byte_windows")]
 
 
 class HgSynthSpec(ctypes.Structure):

@@ -155,6 +155,7 @@ typedef struct hg_db_info {
     uint32_t fold_mask;
     uint32_t max_state_words;
     uint32_t table_bytes;
+    uint32_t byte_windows;       /* 1: the prefilter probes a window at every byte offset (sets with 3..6-byte required literals) */
 } hg_db_info_t;
 
 /* Compile `n` expressions (same inputs as hs_compile_multi).  On failure returns HG_ERR_COMPILE and

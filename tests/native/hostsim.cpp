@@ -70,10 +70,11 @@ uint32_t hgsim_selfcheck(void *h, uint32_t *out) {
     const uint32_t key = hg_hash_window(w.value);
     // the literal as a text of its own, lower-cased where it is case-insensitive (what folding maps both cases to)
     std::vector<uint8_t> text(f.lit, f.lit + f.len);
+    if (f.len < HG_WINDOW_BYTES) text.push_back(static_cast<uint8_t>(w.value >> 24));  // enumerated byte after a 3-byte literal
     auto dword_at = [&](int64_t p) {
       uint32_t x = 0;
       for (int b = 0; b < 4; b++)
-        if (p + b >= 0 && p + b < static_cast<int64_t>(f.len)) x |= static_cast<uint32_t>(text[p + b]) << (8 * b);
+        if (p + b >= 0 && p + b < static_cast<int64_t>(text.size())) x |= static_cast<uint32_t>(text[p + b]) << (8 * b);
       return x;
     };
     if (db->filter_wide) {
@@ -95,12 +96,12 @@ uint32_t hgsim_selfcheck(void *h, uint32_t *out) {
       }
     }
     uint32_t j0, j1;
-    hg_disc_range(v, text.data(), f.len, off, w.value, &j0, &j1);
+    hg_disc_range(v, text.data(), text.size(), off, w.value, &j0, &j1);
     bool found = false;
     for (uint32_t j = j0; j < j1; j++) found = found || (db->windows2[j].value == w.value && db->windows2[j].factor_off == w.factor_off);
     if (!found) bad++;
   }
-  if (out) { out[0] = db->filter_log2; out[1] = db->filter_wide; out[2] = many; }
+  if (out) { out[0] = db->filter_log2; out[1] = db->filter_wide; out[2] = many; out[3] = db->dense; }
   return bad;
 }
 uint32_t hgsim_pattern_tier(void *h, uint32_t i) { return static_cast<HgDb *>(h)->patterns[i].tier; }
@@ -152,19 +153,21 @@ long hgsim_scan(void *h, const uint8_t *data, uint64_t nbytes, int buffer_size, 
   for (uint64_t t = 0; t < ntiles; t++) {
     uint64_t base = t * HG_TILE_BYTES;
     HgTileSum s{0, HG_NONE32, HG_NONE32, 0};
-    for (uint32_t d = 0; d < HG_TILE_BYTES / 4; d++) {
-      uint64_t pos = base + d * 4ull;
+    const uint32_t step = db->dense ? 1 : 4;  // byte-aligned probing: a window starts at every byte
+    for (uint32_t d = 0; d < HG_TILE_BYTES / step; d++) {
+      uint64_t pos = base + static_cast<uint64_t>(d) * step;
       if (pos >= nbytes) break;
       uint32_t w = 0;
       uint64_t avail = nbytes - pos < 4 ? nbytes - pos : 4;
       std::memcpy(&w, data + pos, avail);  // bytes past the end read as zero, as the kernel masks them
       uint32_t rank_here = s.nl_count;
       uint32_t m = hg_newline_mask(w);
+      if (db->dense) m &= 0x80u;  // only the byte at pos itself
       if (m) {
         for (uint32_t b = 0; b < 4; b++)
           if (m >> (8 * b + 7) & 1) {
-            if (s.first_nl == HG_NONE32) s.first_nl = d * 4 + b;
-            s.last_nl = d * 4 + b;
+            if (s.first_nl == HG_NONE32) s.first_nl = d * step + b;
+            s.last_nl = d * step + b;
           }
         s.nl_count += hg_popc(m);
       }
@@ -194,7 +197,7 @@ long hgsim_scan(void *h, const uint8_t *data, uint64_t nbytes, int buffer_size, 
         if (getenv("HGSIM_DUMP")) l1_hist[folded]++;
         const uint32_t pf = dword_at(static_cast<int64_t>(pos) - 4) | v.fold_mask, nf = dword_at(static_cast<int64_t>(pos) + HG_WINDOW_BYTES) | v.fold_mask;
         // the kernel cannot see across its 16 KiB tile edge or the first/last lane of a 1 KiB segment: treat as pass there
-        const bool edge_prev = (pos % 1024) == 0, edge_next = (pos % 1024) == 1020;
+        const bool edge_prev = !db->dense && (pos % 1024) == 0, edge_next = !db->dense && (pos % 1024) == 1020;
         auto pass = [&](uint32_t sl) {
           // the last lane sees at most its own dword's top byte
           return hg_slot_pass(db->ext[sl], folded, pf, nf, edge_prev ? 0u : 0xFFFFFFFFu, edge_next ? (HG_WINDOW_BYTES == 4 ? 0u : 0xFFu) : 0xFFFFFFFFu);

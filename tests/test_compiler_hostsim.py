@@ -46,13 +46,65 @@ def test_flag_and_anchor_rules():
 
 
 def test_tiers_and_factors():
-    db = hgsim_py.Db(["foobar", "needle_in_haystack", "user=[a-z0-9_]{4,12} status=5[0-9]{2}", "[a-z]+@[a-z]+",
-                      "(alpha_long_one|beta_long_two)x", "(?i)CaseLessLiteral"])
+    long_ones = ["needle_in_haystack", "user=[a-z0-9_]{4,12} status=5[0-9]{2}", "[a-z]+@[a-z]+",
+                 "(alpha_long_one|beta_long_two)x", "(?i)CaseLessLiteral"]
+    # required literals of 7 bytes and more: dword-aligned windows, one per residue mod 4
+    db = hgsim_py.Db(long_ones)
     assert db.ok(), db.error
-    assert [db.tier(i) for i in range(6)] == [1, 0, 0, 1, 0, 0]
+    assert [db.tier(i) for i in range(5)] == [0, 0, 1, 0, 0]
     info = db.info()
-    assert info["nslow"] == 2 and info["fold_mask"] == 0x20202020
+    assert info["nslow"] == 1 and info["fold_mask"] == 0x20202020
     assert info["nfactors"] >= 5 and info["nwindows"] == 4 * info["nfactors"]
+    assert db.selfcheck()["byte_windows"] == 0
+    # a 6-byte literal joins: the whole set switches to byte-aligned probing, one window per literal
+    db = hgsim_py.Db(["foobar"] + long_ones)
+    assert db.ok(), db.error
+    assert [db.tier(i) for i in range(6)] == [0, 0, 0, 1, 0, 0]
+    info = db.info()
+    assert info["nslow"] == 1 and info["nwindows"] == info["nfactors"]
+    check = db.selfcheck()
+    assert check["byte_windows"] == 1 and check["violations"] == 0
+    # 3-byte literals: the byte after the literal is enumerated (256 windows, 128 distinct under case folding)
+    db = hgsim_py.Db(["foo", "barbaz"])
+    assert db.ok(), db.error
+    assert [db.tier(i) for i in range(2)] == [0, 0] and db.info()["nwindows"] == 257
+    assert db.selfcheck()["violations"] == 0
+    # 2-byte literals and expressions without a required literal stay on every line
+    db = hgsim_py.Db(["ab", "[0-9]+x"])
+    assert [db.tier(i) for i in range(2)] == [1, 1]
+
+
+def test_short_literals_byte_aligned_windows():
+    """Every alignment of short literals, at the edges of the text, of tiles and of 1 KiB rows, with look-alikes around."""
+    pats = ["ERROR", "WARN", "foo", "(?i)Fail", "a\\.b", "panic: [a-z]+", "x=\\d+;"]
+    flags = [14, 14, 10, 14, 14, 6, 14]
+    ids = [0, 1, 2, 3, 4, 5, 6]
+    db = hgsim_py.Db(pats, flags, ids)
+    assert db.ok(), db.error
+    assert db.selfcheck()["byte_windows"] == 1 and db.selfcheck()["violations"] == 0
+    assert [db.tier(i) for i in range(7)] == [0] * 6 + [1]  # "x=" is too short: that one runs on every line
+    rng = random.Random(77)
+    words = [b"ERROR", b"WARN", b"foo", b"FAIL", b"fAiL", b"a.b", b"panic: oops", b"x=12;", b"ERRO", b"WAR", b"fo", b"fai", b"x=;", b"foofoo"]
+    for trial in range(6):
+        out = bytearray()
+        while len(out) < 40000:
+            line = bytearray()
+            for _ in range(rng.randint(0, 6)):
+                line += rng.choice(words) if rng.random() < 0.5 else bytes(rng.choice(b"abcdefoOrRE =.;0123") for _ in range(rng.randint(1, 9)))
+                if rng.random() < 0.5:
+                    line += b" "
+            out += line + b"\n"
+        # occurrences that straddle 1 KiB rows and the 16 KiB tile edge, and one that ends the text
+        for at in (1021, 1022, 1023, 2045, 16381, 16382, 16383, 32765):
+            out[at:at + 5] = b"ERROR"
+            out[at + 3000:at + 3003] = b"foo"
+        data = bytes(out[:39000 + trial]) + rng.choice([b"foo", b"WARN", b"ERROR\n", b"fo"])
+        want, _ = oracle_hits(data, pats, flags, ids)
+        got, stats = db.scan(data)
+        assert sorted(got) == want, trial
+        tuned = hgsim_py.Db(pats, flags, ids)
+        assert tuned.tune(data[:20000]) == 0 and tuned.selfcheck()["violations"] == 0
+        assert sorted(tuned.scan(data)[0]) == want, trial
 
 
 @pytest.mark.parametrize("seed", range(40))

@@ -581,3 +581,40 @@ def test_always_on_patterns_segment_scan(torch_cuda):
     want2, nlines2 = oracle_hits(data, pats, flags, ids, buffer_size=20000)
     got2, stats2 = gpu_scan_buffer(torch_cuda, data, pats, flags, ids, buffer_size=20000)
     assert stats2.n_lines == nlines2 and got2 == want2
+
+
+@pytest.mark.gpu
+def test_short_literals_byte_aligned_windows(torch_cuda):
+    """Required literals of 3..6 bytes switch the prefilter to byte-aligned probing (one window per literal, 16 probes per
+    16 bytes).  Occurrences at every alignment, across 1 KiB rows, tile edges and the end of the text, NULs, forced breaks."""
+    from hypergrep_amd import device
+
+    pats = ["ERROR", "WARN", "foo", "(?i)Fail", "a\\.b", "panic: [a-z]+", "x=\\d+;", "status=5[0-9]{2}", "\\bGET\\b /api"]
+    flags = [14, 14, 10, 14, 14, 6, 14, 14, 14]
+    ids = [0, 1, 2, 3, 4, 5, 6, 7, 7]
+    info = device.Database(pats, flags, ids).info()
+    assert info["byte_windows"] == 1 and info["n_always_on"] == 1
+    rng = random.Random(78)
+    words = [b"ERROR", b"WARN", b"foo", b"FAIL", b"fAiL", b"a.b", b"panic: oops", b"x=12;", b"ERRO", b"WAR", b"fo", b"fai", b"x=;", b"foofoo",
+             b"status=503", b"status=200", b"GET /api", b"GETS /api"]
+    for trial in range(3):
+        out = bytearray()
+        while len(out) < 300000:
+            line = bytearray()
+            for _ in range(rng.choice([0, 2, 6, 6, 40])):
+                line += rng.choice(words) if rng.random() < 0.4 else bytes(rng.choice(b"abcdefoOrRE =.;0123") for _ in range(rng.randint(1, 9)))
+                if rng.random() < 0.5:
+                    line += b" "
+            if rng.random() < 0.02:
+                line[len(line) // 2:len(line) // 2] = b"\0"
+            out += line + b"\n"
+        out[100000:100000] = b"z" * 30000 + b" ERROR foo " + b"y" * 20000  # one line longer than a tile
+        for at in (1021, 1022, 1023, 2045, 16381, 16382, 16383, 32765, 65533):
+            out[at:at + 5] = b"ERROR"
+            out[at + 3000:at + 3003] = b"foo"
+        data = bytes(out[:290000 + trial]) + rng.choice([b"foo", b"WARN", b"ERROR\n", b"fo"])
+        for bs in (262140, 4096):
+            want, nlines = oracle_hits(data, pats, flags, ids, buffer_size=bs)
+            got, stats = gpu_scan_buffer(torch_cuda, data, pats, flags, ids, buffer_size=bs)
+            assert stats.n_lines == nlines and got == want, (trial, bs)
+        assert len(want) > 3000
