@@ -5,7 +5,7 @@ import torch
 from hypergrep_amd import benchspec, device
 patterns, needles, hpm = benchspec.c3_spec()
 for pats in (["ERROR"], ["foo|bar"], ["status=5[0-9]{2}"], ["ERROR", "WARN", "panic", "fail"], ["[0-9]+\\.[0-9]+"], ["fail.*time"], ["\\bGET\\b"]):
-    nbytes = 1 << 30
+    nbytes = int(sys.argv[1]) << 30 if len(sys.argv) > 1 else 1 << 30
     text = torch.empty(nbytes + 64, dtype=torch.uint8, device="cuda:0")
     device.synth_device(text.data_ptr(), nbytes, 77, needles, hpm)
     torch.cuda.synchronize()
@@ -17,4 +17,4 @@ for pats in (["ERROR"], ["foo|bar"], ["status=5[0-9]{2}"], ["ERROR", "WARN", "pa
     for _ in range(3):
         st = sc.scan(text.data_ptr(), nbytes)
     dt = (time.perf_counter() - t) / 3
-    print(f"  {nbytes / (1 << 30) / dt:8.1f} GiB/s  hits={st.n_hits} lines={st.n_lines}")
+    print(f"  {nbytes / (1 << 30) / dt:8.1f} GiB/s  hits={st.n_hits} lines={st.n_lines} cands={st.n_candidates} stream={st.ms_stream:.3f} ms ({nbytes / 1e9 / max(st.ms_stream, 1e-9):.0f} GB/s) total={st.ms_total:.3f} ms")
