@@ -519,20 +519,24 @@ def test_random_literal_anchored_patterns_match_oracle(torch_cuda, seed):
     assert len(want) > 500
 
 
-@pytest.mark.parametrize("mib, chunk_tiles, seed", [(97, 1024, 1), (333, 4096, 2), (700, 8192, 3), (1311, 16384, 4)])
-def test_chunked_pipeline_equals_single_pass(torch_cuda, monkeypatch, mib, chunk_tiles, seed):
+@pytest.mark.parametrize("mib, chunk_tiles, seed, extra", [(97, 1024, 1, []), (333, 4096, 2, []), (700, 8192, 3, []), (1311, 16384, 4, []),
+                                                            (211, 2048, 5, ["retry", "=77", "=7[0-9]? "])])
+def test_chunked_pipeline_equals_single_pass(torch_cuda, monkeypatch, mib, chunk_tiles, seed, extra):
     """The chunked two-stream pipeline (early sort of the first chunks + merge, carried line numbers, double-buffered
     candidates) and the single pass must deliver identical records, for chunk counts from 3 to 6 and ragged sizes."""
     from hypergrep_amd import benchspec, device
 
     torch = torch_cuda
     patterns, needles, hpm = benchspec.c3_spec()
+    patterns = patterns + extra  # short literals: byte-aligned probing plus an always-on expression in the chunked pipeline
     ids = list(range(len(patterns)))
     nbytes = (mib << 20) + 12345 * seed
     text = torch.empty(nbytes + 64, dtype=torch.uint8, device="cuda:0")
     device.synth_device(text.data_ptr(), nbytes, 5000 + seed, needles, hpm * 2)
     torch.cuda.synchronize()
-    sc = device.Scanner(device.Database(patterns, ids=ids), 0)
+    db = device.Database(patterns, ids=ids)
+    assert db.info()["byte_windows"] == (1 if extra else 0)
+    sc = device.Scanner(db, 0)
 
     def run():
         st = sc.scan(text.data_ptr(), nbytes, line_base=77)
