@@ -332,7 +332,17 @@ __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, 
 
   auto load_chunk = [&](int it) -> uint4 {
     const uint64_t g = chunk0 + static_cast<uint64_t>(it) * 64u;
-    if (FULL) return text16[g];
+    if (FULL) {
+      // streaming (non-temporal) cache policy: the text is read once and must not push the filter's second level, the
+      // tile summaries and the side passes' working set out of the L2 (measured: 5.0 -> 5.4 TB/s in the pipeline)
+#if defined(HG_NO_NT_LOADS)
+      return text16[g];
+#else
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(text16) + g);
+      return make_uint4(v.x, v.y, v.z, v.w);
+#endif
+    }
     return load_chunk_checked(text16, nbytes, g);
   };
 
@@ -471,8 +481,14 @@ __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, 
 #ifndef HG_STREAM_WAVES
 #define HG_STREAM_WAVES 6
 #endif
-// DEPTH: 16-byte loads in flight per lane.  Measured: with three workgroups resident per CU one is best (more thrashes), with
-// two (next to the side passes of the chunked pipeline) three.
+#ifndef HG_DEPTH_ALONE
+#define HG_DEPTH_ALONE 3
+#endif
+#ifndef HG_DEPTH_SHARED
+#define HG_DEPTH_SHARED 3
+#endif
+// DEPTH: 16-byte loads in flight per lane.  With non-temporal loads three is best for both kinds of launch (before, a launch
+// that had three workgroups per CU to itself did better with one: deeper prefetch thrashed the L2).
 template <int LOG2, bool WIDE, bool DENSE, int DEPTH>
 __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_STREAM_WAVES, 8))) void hg_stream_kernel(const uint4 *__restrict__ text16, uint64_t nbytes, uint64_t tile_begin, uint64_t tile_end,
                                                                   const uint4 *__restrict__ filter16, const uint4 *__restrict__ ext16,
@@ -542,13 +558,13 @@ void launch_depth(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
 template <int L, bool W, bool B>
 void launch_one(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
   // filters up to 16 KiB leave room for three workgroups per CU: a launch that has the chip to itself prefetches one chunk ahead
-  if (!W && !B && L <= 12 && a.alone) launch_depth<L, W, B, (!W && !B && L <= 12) ? 1 : 3>(a, grid, stream);
-  else launch_depth<L, W, B, 3>(a, grid, stream);
+  if (!W && !B && L <= 12 && a.alone) launch_depth<L, W, B, (!W && !B && L <= 12) ? HG_DEPTH_ALONE : HG_DEPTH_SHARED>(a, grid, stream);
+  else launch_depth<L, W, B, HG_DEPTH_SHARED>(a, grid, stream);
 }
 template <int L, bool W, bool B>
 int blocks_one() {
   int n = 0;
-  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (hg_stream_kernel<L, W, B, 3>), WG_THREADS, 0);
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (hg_stream_kernel<L, W, B, HG_DEPTH_SHARED>), WG_THREADS, 0);
   return n > 0 ? n : 1;
 }
 }  // namespace
