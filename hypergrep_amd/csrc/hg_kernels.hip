@@ -8,7 +8,9 @@
 //   hg_tile_*             3-launch scan of the tile newline summaries -> global piece numbers
 //   hg_verify_kernel      (candidate, literal) pairs flattened over the wave: one straight-line literal compare per lane
 //   hg_confirm_*          verified occurrences by automaton shape: locate the line piece, run the automaton, emit hits
-//   hg_always_on_kernel   patterns without a long enough required literal: every line, one wave per tile
+//   hg_always_on_*        patterns without a usable required literal: segment-parallel automata over every byte (256 bytes
+//                         per lane, tables in LDS), a finish kernel that locates the lines of the noted matches, and the
+//                         scalar routine for automata of more than two state words
 //   hg_key/keep/scatter   ordering + SINGLEMATCH / duplicate rules (sort itself: rocPRIM radix sort)
 //
 // Byte/integer work, HBM-bound: no MFMA anywhere.  Wave64 only.
@@ -38,13 +40,12 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lan
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
-// Stream pass.  One wave owns one 16 KiB tile at a time; tiles are dealt round-robin over all resident
-// waves so that at any moment the chip streams one contiguous window of the text.
+// Stream pass.  One wave owns one 16 KiB tile at a time; every workgroup streams its own consecutive range of tiles.
 //
-// Per 16 bytes of text a lane spends: 1 coalesced 16 B load, 4 x (4 ops: exact newline count) and
-// 4 x (fold, 3 x v_dot4_u32_u8, 2 LDS u16 reads, 2 compares) for the window filter.  Ranks and the append
-// to the candidate buffer run only in iterations where some lane's fingerprint matched (~1e-5 per dword
-// plus the real occurrences), so the steady state is pure streaming.
+// Per 16 bytes of text a lane spends: 1 coalesced 16 B load (non-temporal), 4 x (4 ops: exact newline count) and
+// 4 x (fold, 2 x v_dot4_u32_u8, 1 LDS read, 2 SDWA ops) for the window filter — 16 x with byte-aligned probing.  A chunk
+// whose filter matched is queued in LDS; ranks, second level and the append to the candidate segment run out of line
+// for 64 queued chunks at a time, so the steady state is pure streaming.
 namespace {
 
 // "not a newline" bits: bit 7 of each byte is CLEAR iff that byte is '\n' (exact, no carries between bytes)
@@ -1079,7 +1080,6 @@ __global__ __launch_bounds__(HG_CONFIRM_THREADS) void hg_confirm_fast_kernel(HgC
 }
 __global__ __launch_bounds__(256) void hg_confirm_generic_kernel(HgConfirmArgs a) { confirm_body<3>(a, blockIdx.x, gridDim.x); }
 
-// Always-on tier: one wave per tile, each lane owns 256 bytes and handles the lines that START there.
 // Scalar always-on pass over the entries [first, last) of the always-on list (patterns of more than two state words).
 __global__ __launch_bounds__(256) void hg_always_on_kernel(HgConfirmArgs a, uint32_t first, uint32_t last) {
   __shared__ uint32_t s_n, s_base;
