@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <thread>
 #include <cstdio>
@@ -347,19 +348,25 @@ class Reader {
 // ---------------------------------------------------------------- result ring (hyperscanner.c:64-72, :83-102)
 struct Ring {
   std::vector<hyperscanner_result_t> slots;
-  std::vector<char> storage;
+  char *storage = nullptr;  // buffer_count line buffers of buffer_size bytes (hyperscanner.c:277-291); malloc, not a zero-filled
+                            // vector: with a large buffer_count most of it is never touched (1 GiB for 4096 x 262140)
   int fill = 0;
   hs_event cb = nullptr;
   unsigned long long delivered = 0;
+  Ring() = default;
+  Ring(const Ring &) = delete;
+  Ring &operator=(const Ring &) = delete;
+  ~Ring() { std::free(storage); }
   bool init(int count, int buffer_size, hs_event on_event) {
     cb = on_event;
     try {
       slots.resize(static_cast<size_t>(count));
-      storage.resize(static_cast<size_t>(count) * static_cast<size_t>(buffer_size));
     } catch (const std::bad_alloc &) {
       return false;
     }
-    for (int i = 0; i < count; i++) slots[i].line = storage.data() + static_cast<size_t>(i) * static_cast<size_t>(buffer_size);
+    storage = static_cast<char *>(std::malloc(static_cast<size_t>(count) * static_cast<size_t>(buffer_size)));
+    if (!storage) return false;
+    for (int i = 0; i < count; i++) slots[i].line = storage + static_cast<size_t>(i) * static_cast<size_t>(buffer_size);
     return true;
   }
   void push(unsigned id, unsigned long long line_number, const uint8_t *line, uint32_t len) {
@@ -439,6 +446,12 @@ extern "C" int hyperscan(char *file_name, const char *const *patterns, const uns
     int state = 0;      // 0 free (reader's), 1 ready (consumer's)
   };
   Slot slots[Ctx::kSlots];
+  // HYPERGREP_TRACE=1: where the call's wall time went (seconds), printed to stderr at the end
+  const bool trace = std::getenv("HYPERGREP_TRACE") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_call = now();
+  double t_read = 0, t_wait_slot = 0, t_scan = 0, t_deliver = 0;  // reader: filling slots; consumer: waiting for a slot, copy + scan + hit copy, ring + callbacks
+  uint64_t bytes_in = 0;
   std::mutex mu;
   std::condition_variable cv;
   bool abandon = false;  // the consumer stopped early (match limit, error)
@@ -456,6 +469,7 @@ extern "C" int hyperscan(char *file_name, const char *const *patterns, const uns
       size_t have = carry.size();
       if (have) std::memcpy(buf, carry.data(), have);
       carry.clear();
+      const double t_fill = now();
       while (!eof && have < cap) {
         const long got = in.read(buf + have, cap - have);
         if (got <= 0) {  // end of the stream; a read error ends it like gzgets returning NULL
@@ -464,6 +478,7 @@ extern "C" int hyperscan(char *file_name, const char *const *patterns, const uns
         }
         have += static_cast<size_t>(got);
       }
+      t_read += now() - t_fill;
       size_t cut = have;
       if (!eof && have) {  // cut at a piece boundary so that every piece is scanned whole
         const void *nl = memrchr(buf, '\n', have);
@@ -509,14 +524,18 @@ extern "C" int hyperscan(char *file_name, const char *const *patterns, const uns
     Slot &s = slots[sl];
     bool next_ready = false;
     {
+      const double t0 = now();
       std::unique_lock<std::mutex> lock(mu);
       cv.wait(lock, [&] { return s.state == 1; });
+      t_wait_slot += now() - t0;
       next_ready = nslots > 1 && !s.last && slots[(k + 1) % nslots].state == 1;
     }
     const uint8_t *host = ctx->h_slot[sl];
     const size_t cut = s.cut;
     const bool last = s.last;
     if (cut) {
+      const double t_begin = now();
+      bytes_in += cut;
       uint8_t *d_text = ctx->d_text[nslots > 1 ? k % Ctx::kDevBufs : 0];
       if (!issue_copy(k) || (next_ready && !issue_copy(k + 1)) ||  // the next chunk travels while this one is scanned
           hipStreamWaitEvent(ctx->stream, ctx->ev_h2d[k % Ctx::kDevBufs], 0) != hipSuccess) {
@@ -540,6 +559,8 @@ extern "C" int hyperscan(char *file_name, const char *const *patterns, const uns
           break;
         }
       }
+      const double t_scanned = now();
+      t_scan += t_scanned - t_begin;
       // deliver line by line; inside a line reports go out by ascending end offset, then id (hs_scan order)
       size_t i = 0;
       while (i < ctx->hits.size() && !stop) {
@@ -561,6 +582,7 @@ extern "C" int hyperscan(char *file_name, const char *const *patterns, const uns
         i = j;
       }
       line_base += out.n_pieces;
+      t_deliver += now() - t_scanned;
     }
     copied[sl] = false;
     {
@@ -573,5 +595,8 @@ extern "C" int hyperscan(char *file_name, const char *const *patterns, const uns
   stop_reader();
   (void)hipStreamSynchronize(ctx->copy_stream);  // a copy issued ahead may still be in flight
   ring.flush();
+  if (trace)
+    std::fprintf(stderr, "[hypergrep_amd] %s: %.1f MiB in %.4f s; reader filling slots %.4f s; consumer: waiting for data %.4f s, copy + scan %.4f s, delivering %llu hits %.4f s\n",
+                 file_name, bytes_in / 1048576.0, now() - t_call, t_read, t_wait_slot, t_scan, static_cast<unsigned long long>(ring.delivered), t_deliver);
   return rc;
 }
