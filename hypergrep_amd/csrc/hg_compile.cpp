@@ -911,16 +911,17 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
   std::vector<std::pair<uint32_t, HgWindow>> keyed;
   std::vector<uint32_t> next16_of;  // per keyed entry: hg_next16 of the two bytes after the window, 0 if unknown
   const uint32_t fold = db.fold_mask;
+  const uint32_t wbytes = db.window_bytes, wmask = db.window_mask;
   for (uint32_t fi = 0; fi < db.nreal_factors; fi++) {
     const HgFactor &fct = db.factors[fi];
     Lit l{std::string(reinterpret_cast<const char *>(fct.lit), fct.len), std::string(reinterpret_cast<const char *>(fct.cmask), fct.len)};
-    if (db.dense && fct.len < HG_WINDOW_BYTES) {
+    if (db.dense && fct.len < wbytes) {
       // a literal one byte short of a window: every value of the byte after it (the stream pass reads zeros past the text)
       std::vector<uint32_t> seen;
       for (uint32_t last = 0; last < 256; last++) {
         uint32_t v = 0;
         std::memcpy(&v, fct.lit, fct.len);
-        v = ((v | (last << 24)) | fold) & HG_WINDOW_MASK;
+        v = ((v | (last << 24)) | fold) & wmask;
         if (std::find(seen.begin(), seen.end(), v) != seen.end()) continue;  // folding maps two bytes onto one value
         seen.push_back(v);
         keyed.push_back({hg_hash_window(v), HgWindow{v, fi << 8}});
@@ -937,25 +938,25 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
       int best = -1;
       long best_cost = 0;
       int best_sel = -1;
-      for (uint32_t o = res; o + HG_WINDOW_BYTES <= fct.len; o += db.dense ? 1 : 4) {
+      for (uint32_t o = res; o + wbytes <= fct.len; o += db.dense ? 1 : 4) {
         uint32_t v = 0;
-        std::memcpy(&v, fct.lit + o, HG_WINDOW_BYTES);
-        v = (v | fold) & HG_WINDOW_MASK;
+        std::memcpy(&v, fct.lit + o, wbytes);
+        v = (v | fold) & wmask;
         long cost = 0;
         if (stats) {  // the hot path compares the window dword alone: its frequency in the sample is what costs
           auto it = stats->c4.find(v);
           cost = it == stats->c4.end() ? 0 : it->second;
         }
         int sel = 0;
-        for (int j = static_cast<int>(o); j < static_cast<int>(o + HG_WINDOW_BYTES); j++) sel += 11 - byte_commonness(static_cast<unsigned char>(l.bytes[j]));
+        for (int j = static_cast<int>(o); j < static_cast<int>(o + wbytes); j++) sel += 11 - byte_commonness(static_cast<unsigned char>(l.bytes[j]));
         for (int j = std::max(static_cast<int>(o) - 4, 0); j < std::min<int>(o + 7, fct.len); j++)
           sel += (11 - byte_commonness(static_cast<unsigned char>(l.bytes[j]))) / 4;
         if (best < 0 || cost < best_cost || (cost == best_cost && sel > best_sel)) { best = static_cast<int>(o); best_cost = cost; best_sel = sel; }
       }
       if (best < 0) continue;  // cannot happen for len >= HG_FAST_MIN_FACTOR
       uint32_t v = 0;
-      std::memcpy(&v, fct.lit + best, HG_WINDOW_BYTES);
-      v = (v | fold) & HG_WINDOW_MASK;  // case-insensitive positions hold lower-case letters already; folding maps both cases onto them
+      std::memcpy(&v, fct.lit + best, wbytes);
+      v = (v | fold) & wmask;  // case-insensitive positions hold lower-case letters already; folding maps both cases onto them
       keyed.push_back({hg_hash_window(v), HgWindow{v, (fi << 8) | static_cast<uint32_t>(best)}});
       next16_of.push_back(0);
     }
@@ -1047,8 +1048,8 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
   {
     std::vector<uint32_t> cand_weights;
     for (uint32_t i = 0; i < HG_SLOT_WEIGHT_NCHOICES; i++) {
-      cand_weights.push_back(HG_SLOT_WEIGHT_CHOICES[i][0]);
-      cand_weights.push_back(HG_SLOT_WEIGHT_CHOICES[i][1]);
+      cand_weights.push_back(HG_SLOT_WEIGHT_CHOICES[i][0] & wmask);  // (3-byte windows: the dword's top byte has weight zero)
+      cand_weights.push_back(HG_SLOT_WEIGHT_CHOICES[i][1] & wmask);
     }
     auto slot_words = [&](uint32_t k, uint32_t weights, std::vector<uint32_t> &words) -> double {
       const uint32_t byte_mask = ((1u << k) - 1u) << 2;
@@ -1114,7 +1115,7 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
         const int o = static_cast<int>(w.factor_off & 0xff);
         uint32_t pv = 0, pm = 0, nv = 0, nm = 0;
         for (int b = 0; b < 4; b++) {
-          int jp = o - 4 + b, jn = o + static_cast<int>(HG_WINDOW_BYTES) + b;
+          int jp = o - 4 + b, jn = o + static_cast<int>(wbytes) + b;
           if (jp >= 0) { pv |= static_cast<uint32_t>(f.lit[jp]) << (8 * b); pm |= 0xFFu << (8 * b); }
           if (jn < static_cast<int>(f.len)) { nv |= static_cast<uint32_t>(f.lit[jn]) << (8 * b); nm |= 0xFFu << (8 * b); }
         }
@@ -1122,7 +1123,7 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
         nv = (nv | fold) & nm;
         if (!fold) {  // case-insensitive letters cannot be compared exactly without folding: drop them
           for (int b = 0; b < 4; b++) {
-            int jp = o - 4 + b, jn = o + static_cast<int>(HG_WINDOW_BYTES) + b;
+            int jp = o - 4 + b, jn = o + static_cast<int>(wbytes) + b;
             if (jp >= 0 && f.cmask[jp] != 0xFF) { pm &= ~(0xFFu << (8 * b)); pv &= pm; }
             if (jn < static_cast<int>(f.len) && f.cmask[jn] != 0xFF) { nm &= ~(0xFFu << (8 * b)); nv &= nm; }
           }
@@ -1360,8 +1361,11 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
   // every residue mod 4).  When that leaves patterns with shorter literals behind, the stream pass probes a window at
   // every BYTE offset instead (db.dense: four times the probes, a third of the streaming rate — still several times the
   // always-on tier), which takes literals down to HG_DENSE_MIN_FACTOR bytes.
-  auto assign = [&](uint32_t min_factor, uint32_t dense) -> int {
+  auto assign = [&](uint32_t min_factor, uint32_t dense, uint32_t window_bytes) -> int {
     db->dense = dense;
+    db->window_bytes = window_bytes;
+    db->window_mask = window_bytes == 4 ? 0xFFFFFFFFu : 0x00FFFFFFu;
+    db->weights_c = HG_HASH_WEIGHTS & db->window_mask;
     db->slow.clear();
     db->factors.clear();
     db->fold_mask = 0;
@@ -1409,10 +1413,12 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
   }
   int rc = -5;
   if (shortest != SIZE_MAX && !std::getenv("HG_NO_BYTE_WINDOWS")) {
-    rc = assign(static_cast<uint32_t>(shortest), 1);
-    if (rc == -5 && shortest < HG_WINDOW_BYTES) rc = assign(HG_WINDOW_BYTES, 1);  // without the enumerated short literals
+    rc = assign(static_cast<uint32_t>(shortest), 1, HG_WINDOW_BYTES);
+    // too many 3-byte literals to enumerate the byte after each: every window shrinks to 3 bytes instead
+    if (rc == -5 && shortest < HG_WINDOW_BYTES) rc = assign(static_cast<uint32_t>(shortest), 1, HG_WINDOW_BYTES - 1);
+    if (rc == -5 && shortest < HG_WINDOW_BYTES) rc = assign(HG_WINDOW_BYTES, 1, HG_WINDOW_BYTES);  // without the short literals
   }
-  if (rc == -5) rc = assign(HG_FAST_MIN_FACTOR, 0);
+  if (rc == -5) rc = assign(HG_FAST_MIN_FACTOR, 0, HG_WINDOW_BYTES);
   if (rc != 0) {
     if (bad_index) *bad_index = -1;
     return -4;
@@ -1429,7 +1435,7 @@ int hgc_tune(HgDb *db, const uint8_t *sample, size_t nbytes, std::string *err) {
     uint32_t w, nx = 0;
     std::memcpy(&w, sample + p, 4);
     if (p + 8 <= nbytes) std::memcpy(&nx, sample + p + 4, 4);
-    w = (w | fold) & HG_WINDOW_MASK;
+    w = (w | fold) & db->window_mask;
     nx |= fold;
     st.c4[w]++;
     st.c6[static_cast<uint64_t>(w) | (static_cast<uint64_t>(nx & 0xFFFFu) << 32)]++;

@@ -21,6 +21,9 @@ struct HgDb {
   std::vector<uint32_t> filter;      // 1 << filter_log2 slots holding hash C of the owning window (staged in LDS by the stream kernel)
   uint32_t filter_log2 = HG_FILTER_MIN_LOG2;
   uint32_t filter_wide = 0;          // 1: two 16-bit fingerprints per slot, no neighbour conditions (large pattern sets)
+  uint32_t window_bytes = HG_WINDOW_BYTES;  // bytes of a window: 4, or 3 with byte-aligned probing when 3-byte literals are too many to enumerate
+  uint32_t window_mask = HG_WINDOW_MASK;
+  uint32_t weights_c = HG_HASH_WEIGHTS;     // hash C weights (the top weight is zero for 3-byte windows: that byte is not part of the window)
   uint32_t dense = 0;                // 1: the stream pass probes a window at every byte offset, one window per literal (sets with short literals)
   uint32_t weights_a = HG_SLOT_WEIGHT_CHOICES[0][0], weights_b = HG_SLOT_WEIGHT_CHOICES[0][1];
   std::vector<HgSlotInfo> ext;       // per filter slot: the window values in it and their neighbour-dword conditions (second-level check)

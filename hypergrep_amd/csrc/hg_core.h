@@ -54,6 +54,7 @@ struct HgDbView {
   const HgWindow *windows2;
   const uint32_t *slow;
   uint32_t npatterns, nslow, fold_mask;
+  uint32_t window_mask;  // 0xFFFFFFFF, or 0x00FFFFFF for 3-byte windows
   uint32_t nslow_fast;  // the first nslow_fast entries of `slow` have <= 2 state words: hg_always_on_fast_kernel takes them
 };
 
@@ -127,7 +128,7 @@ HG_HD void hg_disc_range(const HgDbView &db, const uint8_t *text, uint64_t nbyte
 template <typename Emit>
 HG_HD void hg_verify_window(const HgDbView &db, const uint8_t *text, uint64_t nbytes, uint64_t pos, uint32_t w,
                             Emit &&emit) {
-  uint32_t folded = (w | db.fold_mask) & HG_WINDOW_MASK;
+  uint32_t folded = (w | db.fold_mask) & db.window_mask;
   uint32_t j0, j1;
   hg_disc_range(db, text, nbytes, pos, folded, &j0, &j1);
   for (uint32_t j = j0; j < j1; j++) {

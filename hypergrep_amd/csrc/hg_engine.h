@@ -45,6 +45,7 @@ struct HgStreamArgs {
   uint32_t weights_a, weights_b;
   uint32_t filter_wide;
   uint32_t dense;  // byte-aligned probing (HgDb::dense)
+  uint32_t weights_c;  // hash C weights (HgDb::weights_c)
   uint32_t alone;  // no other kernel runs next to this launch (every workgroup slot is its own)
   uint32_t span;  // tiles per workgroup when each owns a consecutive range, 0 = round-robin (hg_stream_kernel)
   uint32_t *counters;

@@ -109,6 +109,7 @@ int HgScanner::create(const HgDb *db, int device, HgScanner **out, std::string *
   s->view_.nslow = static_cast<uint32_t>(db->slow.size());
   s->view_.nslow_fast = db->nslow_fast;
   s->view_.fold_mask = db->fold_mask;
+  s->view_.window_mask = db->window_mask;
   HG_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_counters_), HG_CNT_WORDS * 4), "alloc counters");
   HG_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_selected_), 16), "alloc counters");
   HG_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_final_), sizeof(HgTileBase)), "alloc state");
@@ -317,6 +318,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       sa.weights_b = db_->weights_b;
       sa.filter_wide = db_->filter_wide;
       sa.dense = db_->dense;
+      sa.weights_c = db_->weights_c;
       // every workgroup streams its own consecutive range of tiles: same HBM rate as dealing tiles round-robin (measured),
       // and the verify / confirm passes then find neighbouring lines in neighbouring lanes (confirm 1.8 -> 1.5 ms per 32 GiB)
       sa.span = static_cast<uint32_t>(((t1 - t0 + wgs_c - 1) / wgs_c + STREAM_WG_WAVES - 1) / STREAM_WG_WAVES * STREAM_WG_WAVES);

@@ -107,7 +107,7 @@ struct ProbeBytes {
   static constexpr uint32_t BYTE_MASK = ((1u << LOG2) - 1u) << 2;
   // ANY_ONLY: non-zero iff any of the 16 windows matched; else bit k = the window that starts at byte k matched
   template <bool ANY_ONLY>
-  __device__ __forceinline__ static uint32_t probe16(const lds_u32 *filter, uint32_t fold, uint32_t wa, uint4 v, uint32_t nxt) {
+  __device__ __forceinline__ static uint32_t probe16(const lds_u32 *filter, uint32_t fold, uint32_t wa, uint32_t wc, uint4 v, uint32_t nxt) {
     const uint32_t d[5] = {v.x | fold, v.y | fold, v.z | fold, v.w | fold, nxt | fold};
     uint32_t bits = 0;
 #pragma unroll
@@ -120,7 +120,7 @@ struct ProbeBytes {
       for (int k = 0; k < 4; k++) t[k] = Probe<LOG2, false>::at(filter, hg_dot4(w[k], wa) & BYTE_MASK);
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const bool m = hg_slot_match(t[k], hg_dot4(w[k], HG_HASH_WEIGHTS));
+        const bool m = hg_slot_match(t[k], hg_dot4(w[k], wc));  // (3-byte windows: both weight vectors end in zero)
         if (ANY_ONLY) bits |= m ? 1u : 0u;
         else bits |= m ? (1u << (j * 4 + k)) : 0u;
       }
@@ -149,6 +149,7 @@ struct StreamCtx {
   lds_u32 *cand_count;         // the workgroup's candidate counter
   HgCand *seg;                 // the workgroup's private candidate segment
   uint32_t seg_cap, fold, wa, wb;
+  uint32_t wc, wmask;          // byte-aligned probing: hash C weights and the window's byte mask (3- or 4-byte windows)
 };
 
 // Chunk `g` of the text with the bytes past the end of the text zeroed.
@@ -204,7 +205,8 @@ __device__ __noinline__ void drain_batch(const StreamCtx cx, uint32_t first, uin
       rank = e_lo >> 10;
       cur = load_chunk_checked(cx.text16, cx.nbytes, g);
       nxt = load_dword_checked(cx.text16, cx.nbytes, (g + 1) << 4);
-      const uint32_t l1 = ProbeBytes<LOG2>::template probe16<false>(cx.filter, cx.fold, cx.wa, cur, nxt);
+      const uint32_t l1 = ProbeBytes<LOG2>::template probe16<false>(cx.filter, cx.fold, cx.wa, cx.wc, cur, nxt);
+      const uint32_t wbytes = cx.wmask == 0xFFFFFFFFu ? 4u : 3u;
       constexpr uint32_t BYTE_MASK = ((1u << LOG2) - 1u) << 2;
       const uint8_t *text = reinterpret_cast<const uint8_t *>(cx.text16);
       for (uint32_t todo = l1; todo; todo &= todo - 1) {
@@ -215,14 +217,14 @@ __device__ __noinline__ void drain_batch(const StreamCtx cx, uint32_t first, uin
         uint32_t prev = 0, next = 0;
         if (pos >= 4 && pos + 8 <= cx.nbytes) {
           prev = *reinterpret_cast<const hg_u32_unaligned *>(text + pos - 4);
-          next = *reinterpret_cast<const hg_u32_unaligned *>(text + pos + 4);
+          next = *reinterpret_cast<const hg_u32_unaligned *>(text + pos + wbytes);
         } else {
           for (uint32_t b = 0; b < 4; b++) {
             if (pos + b >= 4) prev |= static_cast<uint32_t>(text[pos + b - 4]) << (8 * b);
-            if (pos + 4 + b < cx.nbytes) next |= static_cast<uint32_t>(text[pos + 4 + b]) << (8 * b);
+            if (pos + wbytes + b < cx.nbytes) next |= static_cast<uint32_t>(text[pos + wbytes + b]) << (8 * b);
           }
         }
-        const uint32_t f = wk | cx.fold;
+        const uint32_t f = (wk | cx.fold) & cx.wmask;
         const HgSlotInfo info = cx.ext[(hg_dot4(f, cx.wa) & BYTE_MASK) >> 2];
         if (hg_slot_pass(info, f, prev | cx.fold, next | cx.fold, 0xFFFFFFFFu, 0xFFFFFFFFu)) hits |= 1u << k;
       }
@@ -375,7 +377,7 @@ __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, 
     bool any;
     if constexpr (DENSE) {
       const uint32_t nxt = __builtin_amdgcn_update_dpp(after, cur.x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);  // lane 63 keeps `after`
-      any = ProbeBytes<LOG2>::template probe16<true>(cx.filter, cx.fold, cx.wa, cur, nxt) != 0;
+      any = ProbeBytes<LOG2>::template probe16<true>(cx.filter, cx.fold, cx.wa, cx.wc, cur, nxt) != 0;
     } else {
       any = Probe<LOG2, WIDE>::template probe4<true>(cx.filter, cx.fold, cx.wa, cx.wb, cur) != 0;
     }
@@ -495,7 +497,8 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_S
                                                                   const uint4 *__restrict__ filter16, const uint4 *__restrict__ ext16,
                                                                   uint32_t fold, uint32_t wa, uint32_t wb, HgTileSum *__restrict__ sums,
                                                                   HgCand *__restrict__ cands, uint32_t seg_cap,
-                                                                  uint32_t *__restrict__ seg_count, uint32_t *__restrict__ counters, uint32_t span) {
+                                                                  uint32_t *__restrict__ seg_count, uint32_t *__restrict__ counters, uint32_t span,
+                                                                  uint32_t wc, uint32_t wmask) {
   // LDS, one block so that the filter starts at offset 0 (its byte offsets then fold into the ds_read instructions):
   //   window hash slots (4 B each) | per-wave chunk queues | candidate counter
   constexpr uint32_t FILTER_U4 = (4u << LOG2) / 16, QUEUE_U4 = WG_WAVES * queue_cap(LOG2) * queue_entry_dw(LOG2, DENSE) * 4 / 16;
@@ -519,6 +522,8 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_S
   cx.fold = fold;
   cx.wa = wa;
   cx.wb = wb;
+  cx.wc = wc;
+  cx.wmask = wmask;
   const uint64_t full_tiles = nbytes >> HG_TILE_SHIFT;
   // Tile order.  span == 0: tiles are dealt round-robin over all waves of the grid (the chip streams one contiguous window).
   // span > 0: workgroup b owns the `span` consecutive tiles from tile_begin + b * span, so that the candidates of a segment
@@ -554,7 +559,7 @@ void launch_depth(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
   const uint4 *f = reinterpret_cast<const uint4 *>(a.filter);
   const uint4 *x = reinterpret_cast<const uint4 *>(a.ext);
   hipLaunchKernelGGL((hg_stream_kernel<L, W, B, D>), dim3(grid), dim3(WG_THREADS), 0, stream, t, a.nbytes, a.tile_begin, a.tile_end, f, x, a.db.fold_mask,
-                     a.weights_a, a.weights_b, a.sums, a.cands, a.cand_seg_cap, a.seg_count, a.counters, a.span);
+                     a.weights_a, a.weights_b, a.sums, a.cands, a.cand_seg_cap, a.seg_count, a.counters, a.span, a.weights_c, a.db.window_mask);
 }
 template <int L, bool W, bool B>
 void launch_one(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
@@ -838,7 +843,7 @@ __global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
     uint32_t j0 = 0, cnt = 0, folded = 0;
     if (i < n) {
       c = cseg[i];
-      folded = (c.word | fold) & HG_WINDOW_MASK;
+      folded = (c.word | fold) & a.db.window_mask;
       // the group's discriminator dword of the text selects the bucket (hg_disc_range, with one aligned dword load)
       const uint32_t h = hg_hash_window(folded);
       const uint32_t d = a.db.disc[h];

@@ -70,7 +70,7 @@ uint32_t hgsim_selfcheck(void *h, uint32_t *out) {
     const uint32_t key = hg_hash_window(w.value);
     // the literal as a text of its own, lower-cased where it is case-insensitive (what folding maps both cases to)
     std::vector<uint8_t> text(f.lit, f.lit + f.len);
-    if (f.len < HG_WINDOW_BYTES) text.push_back(static_cast<uint8_t>(w.value >> 24));  // enumerated byte after a 3-byte literal
+    if (f.len < db->window_bytes) text.push_back(static_cast<uint8_t>(w.value >> 24));  // enumerated byte after a 3-byte literal
     auto dword_at = [&](int64_t p) {
       uint32_t x = 0;
       for (int b = 0; b < 4; b++)
@@ -84,13 +84,13 @@ uint32_t hgsim_selfcheck(void *h, uint32_t *out) {
     } else {
       const uint32_t sl = hg_slot(w.value, db->weights_a, byte_mask) >> 2;
       if (!hg_slot_match(db->filter[sl], key)) bad++;
-      const uint32_t prev = dword_at(static_cast<int64_t>(off) - 4) | db->fold_mask, next = dword_at(static_cast<int64_t>(off) + HG_WINDOW_BYTES) | db->fold_mask;
+      const uint32_t prev = dword_at(static_cast<int64_t>(off) - 4) | db->fold_mask, next = dword_at(static_cast<int64_t>(off) + db->window_bytes) | db->fold_mask;
       // bytes outside the literal are unknown in a real text: try both extremes
       for (uint32_t fill : {0u, 0xFFFFFFFFu}) {
         uint32_t p2 = prev, n2 = next;
         for (int b = 0; b < 4; b++) {
           if (static_cast<int>(off) - 4 + b < 0) p2 = (p2 & ~(0xFFu << (8 * b))) | (fill & (0xFFu << (8 * b)));
-          if (off + HG_WINDOW_BYTES + b >= f.len) n2 = (n2 & ~(0xFFu << (8 * b))) | (fill & (0xFFu << (8 * b)));
+          if (off + db->window_bytes + b >= f.len) n2 = (n2 & ~(0xFFu << (8 * b))) | (fill & (0xFFu << (8 * b)));
         }
         if (!hg_slot_pass(db->ext[sl], w.value, p2 | db->fold_mask, n2 | db->fold_mask, 0xFFFFFFFFu, 0xFFFFFFFFu)) bad++;
       }
@@ -133,6 +133,7 @@ static HgDbView view_of(HgDb *db) {
   v.nslow = db->slow.size();
   v.nslow_fast = db->nslow_fast;
   v.fold_mask = db->fold_mask;
+  v.window_mask = db->window_mask;
   return v;
 }
 
@@ -171,7 +172,7 @@ long hgsim_scan(void *h, const uint8_t *data, uint64_t nbytes, int buffer_size, 
           }
         s.nl_count += hg_popc(m);
       }
-      const uint32_t folded = (w | v.fold_mask) & HG_WINDOW_MASK, byte_mask = ((1u << db->filter_log2) - 1u) << 2;
+      const uint32_t folded = (w | v.fold_mask) & db->window_mask, byte_mask = ((1u << db->filter_log2) - 1u) << 2;
       // bytes outside the text read as zero, like the kernel's masked tail
       auto dword_at = [&](int64_t p) -> uint32_t {
         uint32_t x = 0;
@@ -195,7 +196,7 @@ long hgsim_scan(void *h, const uint8_t *data, uint64_t nbytes, int buffer_size, 
       if (ha || hb) {
         bitmap_hits++;
         if (getenv("HGSIM_DUMP")) l1_hist[folded]++;
-        const uint32_t pf = dword_at(static_cast<int64_t>(pos) - 4) | v.fold_mask, nf = dword_at(static_cast<int64_t>(pos) + HG_WINDOW_BYTES) | v.fold_mask;
+        const uint32_t pf = dword_at(static_cast<int64_t>(pos) - 4) | v.fold_mask, nf = dword_at(static_cast<int64_t>(pos) + db->window_bytes) | v.fold_mask;
         // the kernel cannot see across its 16 KiB tile edge or the first/last lane of a 1 KiB segment: treat as pass there
         const bool edge_prev = !db->dense && (pos % 1024) == 0, edge_next = !db->dense && (pos % 1024) == 1020;
         auto pass = [&](uint32_t sl) {

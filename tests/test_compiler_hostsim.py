@@ -107,6 +107,37 @@ def test_short_literals_byte_aligned_windows():
         assert sorted(tuned.scan(data)[0]) == want, trial
 
 
+def test_many_three_byte_literals_use_three_byte_windows():
+    """More 3-byte literals than the filter can hold with the byte after each enumerated: every window shrinks to 3 bytes
+    (byte-aligned probing, hashes that ignore the dword's top byte) and no pattern falls back to the always-on tier."""
+    rng = random.Random(31)
+    alphabet = "abcdefghijklmnopqrstuvwxyz"
+    words = sorted({"".join(rng.choice(alphabet) for _ in range(3)) for _ in range(400)})
+    pats = words + ["needle", "(?i)MiXeD", "ab[0-9]x", "tail$"]
+    flags = [14] * len(words) + [14, 14, 6, 14]
+    ids = list(range(len(pats)))
+    db = hgsim_py.Db(pats, flags, ids)
+    assert db.ok(), db.error
+    info, check = db.info(), db.selfcheck()
+    assert check["byte_windows"] == 1 and check["violations"] == 0
+    assert info["nslow"] == 0 and info["nwindows"] == info["nfactors"]  # one 3-byte window per literal, nothing enumerated
+    for trial in range(3):
+        out = bytearray()
+        while len(out) < 50000:
+            toks = [rng.choice(words + ["needle", "mixed", "MIXED", "ab7x", "tail", "zz", "q"]) if rng.random() < 0.3
+                    else "".join(rng.choice(alphabet + "  .=") for _ in range(rng.randint(1, 7))) for _ in range(rng.randint(0, 12))]
+            out += (" ".join(toks) + "\n").encode()
+        for at in (1021, 1022, 1023, 16381, 16382, 16383, 32766):
+            out[at:at + 3] = words[at % len(words)].encode()
+        data = bytes(out[:49000 + trial]) + words[trial].encode()[: 2 + (trial & 1)]
+        want, _ = oracle_hits(data, pats, flags, ids)
+        got, _ = db.scan(data)
+        assert sorted(got) == want, trial
+    tuned = hgsim_py.Db(pats, flags, ids)
+    assert tuned.tune(data[:30000]) == 0 and tuned.selfcheck()["violations"] == 0
+    assert sorted(tuned.scan(data)[0]) == want
+
+
 @pytest.mark.parametrize("seed", range(40))
 def test_random_patterns_match_oracle(seed):
     rng = random.Random(5000 + seed)

@@ -622,3 +622,35 @@ def test_short_literals_byte_aligned_windows(torch_cuda):
             got, stats = gpu_scan_buffer(torch_cuda, data, pats, flags, ids, buffer_size=bs)
             assert stats.n_lines == nlines and got == want, (trial, bs)
         assert len(want) > 3000
+
+
+@pytest.mark.gpu
+def test_many_three_byte_literals_three_byte_windows(torch_cuda):
+    """400 three-byte literals: too many to enumerate the byte after each, so the whole set uses 3-byte windows (hash
+    weights with a zero top byte) under byte-aligned probing; nothing may fall back to the always-on tier."""
+    from hypergrep_amd import device
+
+    rng = random.Random(32)
+    alphabet = "abcdefghijklmnopqrstuvwxyz"
+    words = sorted({"".join(rng.choice(alphabet) for _ in range(3)) for _ in range(400)})
+    pats = words + ["needle", "(?i)MiXeD", "ab[0-9]x", "tail$"]
+    flags = [14] * len(words) + [14, 14, 6, 14]
+    ids = list(range(len(pats)))
+    info = device.Database(pats, flags, ids).info()
+    assert info["byte_windows"] == 1 and info["n_always_on"] == 0 and info["n_windows"] == info["n_factors"]
+    out = bytearray()
+    while len(out) < 400000:
+        toks = [rng.choice(words + ["needle", "mixed", "MIXED", "ab7x", "tail", "zz", "q"]) if rng.random() < 0.3
+                else "".join(rng.choice(alphabet + "  .=") for _ in range(rng.randint(1, 7))) for _ in range(rng.randint(0, 12))]
+        line = " ".join(toks)
+        if rng.random() < 0.01:
+            line = line[: len(line) // 2] + "\0" + line[len(line) // 2:]
+        out += (line + "\n").encode()
+    for at in (1021, 1022, 1023, 16381, 16382, 16383, 32766, 65534):
+        out[at:at + 3] = words[at % len(words)].encode()
+    data = bytes(out[:390001]) + words[7].encode()
+    for bs in (262140, 3000):
+        want, nlines = oracle_hits(data, pats, flags, ids, buffer_size=bs)
+        got, stats = gpu_scan_buffer(torch_cuda, data, pats, flags, ids, buffer_size=bs)
+        assert stats.n_lines == nlines and got == want, bs
+    assert len(want) > 20000
