@@ -1274,7 +1274,9 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
       for (auto &w : wanted) intern(w.first, w.second);
       if (nodes.size() > HG_MAX_NODES) throw CompileError("pattern too large");
 
-      uint32_t nn = static_cast<uint32_t>(nodes.size()), nw = (nn + 31) / 32;
+      // (an expression whose every entry condition is contradictory, e.g. \b\Bc, has no nodes: it keeps one all-zero state
+      // word so that every routine sees well-formed tables and simply never matches)
+      uint32_t nn = static_cast<uint32_t>(nodes.size()), nw = nn ? (nn + 31) / 32 : 1;
       HgPattern p{};
       p.id = ids ? ids[cur] : 0;
       p.flags = f;

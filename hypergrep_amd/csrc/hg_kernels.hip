@@ -1182,10 +1182,16 @@ __device__ __forceinline__ void always_on_segment(const AlwaysOnCtx &a, const Hg
   bool reported = false;    // SINGLEMATCH: this lane already reported the current line
   const bool single = p.single != 0;
   const uint32_t acc_all = p.acc_all;
-  uint4 chunk = make_uint4(0, 0, 0, 0);
+  // the lane's text arrives 16 bytes at a time, one load ahead (each is a memory round trip of its own: the lanes of a wave
+  // read 256 bytes apart)
+  auto load16 = [&](uint32_t at) { return (at <= stop && base + at < a.nbytes) ? *reinterpret_cast<const uint4 *>(text + base + at) : make_uint4(0, 0, 0, 0); };
+  uint4 chunk = make_uint4(0, 0, 0, 0), ahead = load16(0);
 #pragma unroll 1
   for (uint32_t off = 0; off <= stop; off += 4) {  // 16-byte loads, a dword per trip: the unrolled body (and its registers) stays small
-    if ((off & 15u) == 0) chunk = base + off < a.nbytes ? *reinterpret_cast<const uint4 *>(text + base + off) : make_uint4(0, 0, 0, 0);
+    if ((off & 15u) == 0) {
+      chunk = ahead;
+      ahead = load16(off + 16);
+    }
     const uint32_t sel = (off >> 2) & 3u;
     const uint32_t v = sel == 0 ? chunk.x : (sel == 1 ? chunk.y : (sel == 2 ? chunk.z : chunk.w));
     // the reach sets of the four bytes do not depend on the automaton state: fetch them ahead of the dependent chain
@@ -1272,13 +1278,162 @@ __device__ __forceinline__ void always_on_segment(const AlwaysOnCtx &a, const Hg
   }
 }
 
+// Single-word automata (<= 32 nodes), the common case of the always-on tier, with the follow step table-driven: fu[t][b] is
+// the union of follow[] over the set bits of byte t of the state word, so a step is <= 4 independent LDS reads instead of a
+// loop over the set bits, and the per-byte work is straight-line selects (newline / NUL / segment edges) with three rarely
+// taken branches (forced break, match to note, match ending with the line).  Same results as always_on_segment<1, *>.
+constexpr uint32_t CT_FU = CT_WORDS;              // fu[4][256]
+constexpr uint32_t AO_TAB_WORDS = CT_WORDS + 1024;  // a wave's table area in hg_always_on_fast_kernel
+__device__ __forceinline__ void stage_follow_unions(hgdev::lds_u32 *tab, uint32_t nnodes, uint32_t lane) {
+  // sixteen lanes per table; a lane fixes the low nibble of the index and walks the high one
+  const uint32_t t = lane >> 4, j = lane & 15u;
+  uint32_t f[8];
+#pragma unroll
+  for (uint32_t b = 0; b < 8; b++) f[b] = 8 * t + b < nnodes ? tab[CT_FOLLOW + 8 * t + b] : 0u;
+  uint32_t low = 0;
+#pragma unroll
+  for (uint32_t b = 0; b < 4; b++) low |= ((j >> b) & 1u) ? f[b] : 0u;
+#pragma unroll
+  for (uint32_t m = 0; m < 16; m++) {
+    uint32_t e = low;
+#pragma unroll
+    for (uint32_t b = 0; b < 4; b++) e |= ((m >> b) & 1u) ? f[4 + b] : 0u;
+    tab[CT_FU + t * 256 + m * 16 + j] = e;
+  }
+}
+
+template <bool SIMPLE>
+__device__ __forceinline__ void always_on_segment1(const AlwaysOnCtx &a, const HgPattern &p, uint32_t pi, const hgdev::lds_u32 *tab, uint64_t lo, uint64_t hi,
+                                                   uint64_t line_start, uint64_t bs1, uint32_t rank_lo) {
+  if (lo >= hi) return;
+  const hgdev::lds_u32 *reach = tab + CT_REACH, *fu = tab + CT_FU, *amask = tab + CT_AMASK, *acct = tab + CT_ACC;
+  const uint8_t *text = a.text;
+  uint64_t q = line_start;  // first byte the automaton sees (always_on_segment)
+  if (p.max_len && p.max_len <= HG_ALWAYS_ON_FAST_MAX_LEN) {
+    const uint32_t lead = p.max_len - 1;
+    q = lo > lead ? lo - lead : 0;
+  } else if (lo - line_start >= bs1) {
+    q = line_start + (lo - line_start) / bs1 * bs1;
+  }
+  const uint64_t base = q & ~15ull;
+  const uint32_t first = static_cast<uint32_t>(q - base), own = static_cast<uint32_t>(lo - base), stop = static_cast<uint32_t>(hi - base);
+  const uint32_t span = stop - first;  // bytes r with r - first < span are consumed; r == stop only lends its context
+  const bool text_ends = hi >= a.nbytes;
+  const uint32_t nt = (p.nnodes + 7u) >> 3;  // follow-union tables in use (wave-uniform)
+  const uint32_t I = SIMPLE ? p.init_word : tab[CT_INIT];
+  const uint32_t acc_all = p.acc_all;
+  const bool single = p.single != 0;
+  uint32_t pc = HG_PC_START;
+  if (q) {
+    const uint32_t before = text[q - 1];
+    pc = (before == '\n' || before == 0) ? HG_PC_START : hg_prev_ctx(before);
+  }
+  constexpr uint32_t NO_BREAK = 0xFFFFFFFFu;
+  const uint32_t bs1c = bs1 < 0x7FFFFFFFull ? static_cast<uint32_t>(bs1) : 0x7FFFFFFFu;
+  auto break_after = [&](uint32_t piece_start_rel) {  // first forced break after a piece that starts at base + piece_start_rel
+    const uint32_t at = piece_start_rel + bs1c;       // (both below 2^31)
+    return at < 0x7FFFFFFFu ? at : NO_BREAK;
+  };
+  uint32_t next_break = NO_BREAK;
+  if (q >= line_start) {
+    const uint64_t d = q - line_start, k = d < bs1 ? 0 : d / bs1;
+    const uint64_t at = line_start + k * bs1 + bs1 - base;
+    next_break = at < 0x7FFFFFFFull ? static_cast<uint32_t>(at) : NO_BREAK;
+    if (k && d == k * bs1) pc = HG_PC_START;
+  }
+  uint32_t rank = rank_lo, S = 0;
+  bool reported = false;
+  // the lane's text arrives 16 bytes at a time, one load ahead (each is a memory round trip of its own: the lanes of a wave
+  // read 256 bytes apart)
+  auto load16 = [&](uint32_t at) { return (at <= stop && base + at < a.nbytes) ? *reinterpret_cast<const uint4 *>(text + base + at) : make_uint4(0, 0, 0, 0); };
+  uint4 chunk = make_uint4(0, 0, 0, 0), ahead = load16(0);
+#pragma unroll 1
+  for (uint32_t off = 0; off <= stop; off += 4) {
+    if ((off & 15u) == 0) {
+      chunk = ahead;
+      ahead = load16(off + 16);
+    }
+    const uint32_t sel = (off >> 2) & 3u;
+    const uint32_t v = sel == 0 ? chunk.x : (sel == 1 ? chunk.y : (sel == 2 ? chunk.z : chunk.w));
+    uint32_t rc[4];
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) rc[i] = reach[(v >> (8 * i)) & 0xFFu];
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+      const uint32_t r = off + i;
+      const bool consume = r - first < span;  // first <= r < stop
+      const bool at_stop = r == stop;
+      const bool inside = consume || at_stop;
+      const uint32_t c = (at_stop && text_ends) ? 0u : ((v >> (8 * i)) & 0xFFu);
+      if (inside && r == next_break) {  // the piece ends before this byte: END context for a match ending here, then a fresh start
+        if (!SIMPLE) {
+          if ((S & acct[pc * 5 + HG_NC_END]) && r > own && !(single && reported)) always_on_note(a, pi, base + r, rank);
+        }
+        S = 0;
+        pc = HG_PC_START;
+        reported = false;
+        next_break = break_after(r);
+      }
+      uint32_t cc = 0;
+      if (!SIMPLE) {
+        // a match can end before this byte; the byte decides the right-hand context (END at a NUL / the end of the text)
+        cc = c == '\n' ? HG_NC_NLFINAL : (hg_is_word(c) ? HG_NC_WORD : HG_NC_OTHER);
+        const uint32_t hit = inside ? (S & acct[pc * 5 + (c == 0 ? static_cast<uint32_t>(HG_NC_END) : cc)]) : 0u;
+        if (hit && !(single && reported)) {
+          reported = true;  // (a match that ends in an earlier segment is that segment's to report; it also settles this line)
+          if (r > own) always_on_note(a, pi, base + r, rank);
+        }
+      }
+      uint32_t T = I | fu[S & 0xFFu];
+      if (nt > 1) T |= fu[256 + ((S >> 8) & 0xFFu)];
+      if (nt > 2) T |= fu[512 + ((S >> 16) & 0xFFu)];
+      if (nt > 3) T |= fu[768 + (S >> 24)];
+      uint32_t Sn = T & rc[i];
+      if (!SIMPLE) Sn &= amask[pc * 4 + cc];
+      if (c == 0) Sn = 0;  // scanned bytes end here (or leading NULs are skipped): start afresh after it
+      S = consume ? Sn : S;
+      if (SIMPLE) {
+        if (consume && (S & acc_all) && !(single && reported)) {
+          reported = true;
+          if (r >= own) always_on_note(a, pi, base + r + 1, rank);
+        }
+      }
+      const bool nl = consume && c == '\n';
+      if (!SIMPLE) {  // a match that includes the newline ends the line: END context
+        if (nl && (S & acct[HG_PC_NL * 5 + HG_NC_END]) && r >= own && !(single && reported)) always_on_note(a, pi, base + r + 1, rank);
+        if (consume) pc = (nl || c == 0) ? static_cast<uint32_t>(HG_PC_START) : hg_prev_ctx(c);
+      }
+      rank += (nl && r >= own) ? 1u : 0u;
+      S = nl ? 0u : S;
+      reported = nl ? false : reported;
+      next_break = nl ? break_after(r + 1) : next_break;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void hg_always_on_fast_kernel(HgConfirmArgs a) {
   __shared__ uint32_t s_n;
-  __shared__ __attribute__((aligned(16))) uint32_t s_tab[4 * CT_WORDS];
+  __shared__ __attribute__((aligned(16))) uint32_t s_tab[4 * AO_TAB_WORDS];
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  hgdev::lds_u32 *tab = (hgdev::lds_u32 *)(&s_tab[0]) + wave * CT_WORDS;
+  hgdev::lds_u32 *tab = (hgdev::lds_u32 *)(&s_tab[0]) + wave * AO_TAB_WORDS;
+  // the tables of pattern j of the always-on list, staged by the wave
+  auto stage = [&](uint32_t j) {
+    const HgPattern &p = a.db.patterns[a.db.slow[j]];
+    __builtin_amdgcn_wave_barrier();  // the previous pattern's tables are no longer read
+    if (p.simple) stage_tables<false>(tab, a.db.pool, p, 1u, lane);
+    else stage_tables<true>(tab, a.db.pool, p, p.nw, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (p.nw == 1) {
+      stage_follow_unions(tab, p.nnodes, lane);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  };
+  const bool one_pattern = a.db.nslow_fast == 1;  // its tables stay staged for the whole kernel
+  if (one_pattern) stage(0);
   // the verified-occurrence lists are free again (their confirm passes ran before this kernel): one segment per block
   const uint32_t list_cap = a.always_list_cap;
   const AlwaysOnCtx cx{a.text, a.nbytes, a.deferred + static_cast<uint64_t>(blockIdx.x) * list_cap, list_cap, (hgdev::lds_u32 *)(&s_n)};
@@ -1313,13 +1468,9 @@ __global__ __launch_bounds__(256) void hg_always_on_fast_kernel(HgConfirmArgs a)
       const uint32_t pi = a.db.slow[j];
       const HgPattern &p = a.db.patterns[pi];
       const bool simple = p.simple != 0;
-      __builtin_amdgcn_wave_barrier();  // the previous pattern's tables are no longer read
-      if (simple) stage_tables<false>(tab, a.db.pool, p, 1u, lane);
-      else stage_tables<true>(tab, a.db.pool, p, p.nw, lane);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      if (simple) always_on_segment<1, true>(cx, p, pi, tab, lo, hi, line_start, a.bs1, rank_lo);
-      else if (p.nw == 1) always_on_segment<1, false>(cx, p, pi, tab, lo, hi, line_start, a.bs1, rank_lo);
+      if (!one_pattern) stage(j);
+      if (simple) always_on_segment1<true>(cx, p, pi, tab, lo, hi, line_start, a.bs1, rank_lo);
+      else if (p.nw == 1) always_on_segment1<false>(cx, p, pi, tab, lo, hi, line_start, a.bs1, rank_lo);
       else always_on_segment<2, false>(cx, p, pi, tab, lo, hi, line_start, a.bs1, rank_lo);
     }
   }

@@ -107,6 +107,21 @@ def test_short_literals_byte_aligned_windows():
         assert sorted(tuned.scan(data)[0]) == want, trial
 
 
+def test_expressions_that_can_never_match():
+    """Contradictory assertions leave an automaton without nodes (found by tools/fuzz_gpu.py: the GPU staged the NEXT
+    pattern's tables for it).  Such an expression compiles, never matches, and does not disturb its neighbours."""
+    pats = ["\\b\\Bc", "[^a]-$", "\\B\\b$(1){1}", "needle_long", "x\\b\\By"]
+    flags = [7, 10, 15, 14, 6]
+    ids = [2, 3, 2, 0, 1]
+    db = hgsim_py.Db(pats, flags, ids)
+    assert db.ok(), db.error
+    assert db.info()["max_nw"] == 1
+    data = b"abc c-\nccc x y 1\nneedle_long c\nx-\n" * 50
+    want, _ = oracle_hits(data, pats, flags, ids)
+    got, _ = db.scan(data)
+    assert sorted(got) == want and {h[1] for h in want} == {0, 3}
+
+
 def test_many_three_byte_literals_use_three_byte_windows():
     """More 3-byte literals than the filter can hold with the byte after each enumerated: every window shrinks to 3 bytes
     (byte-aligned probing, hashes that ignore the dword's top byte) and no pattern falls back to the always-on tier."""

@@ -654,3 +654,19 @@ def test_many_three_byte_literals_three_byte_windows(torch_cuda):
         got, stats = gpu_scan_buffer(torch_cuda, data, pats, flags, ids, buffer_size=bs)
         assert stats.n_lines == nlines and got == want, bs
     assert len(want) > 20000
+
+
+@pytest.mark.gpu
+def test_expressions_that_can_never_match(torch_cuda):
+    """Contradictory assertions (an automaton without nodes) next to ordinary always-on and literal-anchored expressions:
+    found by tools/fuzz_gpu.py — the kernels used to stage the neighbouring pattern's tables for the empty one."""
+    rng = random.Random(41)
+    pats = ["\\b\\Bc", "[^a]-$", "\\B\\b$(1){1}", "needle_long", "x\\b\\By", "[^a]-", "zq"]
+    flags = [7, 10, 15, 14, 6, 10, 10]
+    ids = [2, 3, 2, 0, 1, 4, 5]
+    data = regex_gen.random_text(rng, 3000, final_newline=True) + b"needle_long c- 1\nzq x y\n" * 20
+    for bs in (262140, 64):
+        want, nlines = oracle_hits(data, pats, flags, ids, buffer_size=bs)
+        got, stats = gpu_scan_buffer(torch_cuda, data, pats, flags, ids, buffer_size=bs)
+        assert stats.n_lines == nlines and got == want, bs
+    assert {h[1] for h in want} == {0, 3, 4, 5}
