@@ -15,6 +15,10 @@ import oracle_py  # noqa: E402
 import regex_gen  # noqa: E402
 from test_gpu_parity import gpu_scan_buffer, oracle_hits  # noqa: E402
 
+def regex_gen_escape(word):
+    return "".join("\\" + c if c in ".-=" else c for c in word)
+
+
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
 t0 = time.time()
@@ -23,8 +27,16 @@ last_print = t0
 while time.time() - t0 < budget:
     rng = random.Random(seed)
     seed += 1
-    kind = rng.choice(["random", "random", "anchored", "mixed"])
-    if kind == "random":
+    kind = rng.choice(["random", "random", "anchored", "mixed", "keywords", "keywords"])
+    if kind == "keywords":  # word lists: byte-aligned probing, 3-byte windows, short and long literals side by side
+        lo, hi = rng.choice([(3, 3), (3, 5), (4, 6), (3, 9), (5, 12)])
+        n = rng.choice([2, 8, 40, 300])
+        pats = sorted({"".join(rng.choice(rng.choice(["abc", "abcxyz01", "abcxyz019_-= "])) for _ in range(rng.randint(lo, hi))) for _ in range(n)})
+        pats = [regex_gen_escape(w) for w in pats]
+        if rng.random() < 0.5:
+            pats += [regex_gen.random_pattern(rng) for _ in range(rng.randint(1, 2))]
+        samplers = []
+    elif kind == "random":
         k = rng.randint(1, 6)
         pats = [regex_gen.random_pattern(rng) for _ in range(k)]
         samplers = []
@@ -35,7 +47,7 @@ while time.time() - t0 < budget:
         if kind == "mixed":
             pats += [regex_gen.random_pattern(rng) for _ in range(rng.randint(1, 3))]
     flags = [rng.choice([14, 14, 15, 10, 6, 12, 7, 2]) for _ in pats]
-    ids = [rng.randint(0, 3) for _ in pats]
+    ids = [rng.randint(0, 3) for _ in pats] if rng.random() < 0.7 else list(range(len(pats)))
     if oracle_py.check_patterns(pats, flags=flags) != 0:
         continue
     if samplers:
@@ -54,6 +66,40 @@ while time.time() - t0 < budget:
             b[at:at] = bytes(rng.choice(b"abcx01 ._-") for _ in range(rng.choice([5000, 20000, 40000])))
         data = bytes(b)
     bs = rng.choice([262140, 262140, 8, 64, 1000, 4096, 20000])
+    if rng.random() < 0.25:  # the same case through the file API (Face B): batches, match limit, gzip, several ingest chunks
+        import gzip
+        import tempfile
+
+        import hypergrep_amd
+
+        big = data * rng.choice([1, 1, 3, 12]) if len(data) < 200000 else data
+        count = rng.choice([1, 3, 16, 500])
+        limit = rng.choice([0, 0, 1, 7, 100])
+        fbs = rng.choice([262140, 262140, 64, 1000]) if b"\0" not in big else 262140
+        with tempfile.NamedTemporaryFile(suffix=rng.choice([".log", ".gz"]), dir="/dev/shm", delete=False) as f:
+            path = f.name
+            f.write(gzip.compress(big, 1) if path.endswith(".gz") else big)
+        os.environ["HYPERGREP_CHUNK_MB"] = rng.choice(["1", "1", "256"])
+        try:
+            want_rc, want_rows, want_batches = oracle_py.scan_file(path, pats, flags, ids, buffer_size=fbs, buffer_count=count, max_match_count=limit)
+            rows, batches = [], []
+
+            def on_match(matches, n, rows=rows, batches=batches):
+                batches.append(n)
+                for i in range(n):
+                    rows.append((matches[i].line_number, matches[i].id, matches[i].line))
+
+            rc = hypergrep_amd.scan(path, pats, on_match, flags=flags, ids=ids, buffer_size=fbs, buffer_count=count, max_match_count=limit)
+        finally:
+            os.unlink(path)
+        cases += 1
+        if (rc, rows, batches) != (want_rc, want_rows, want_batches):
+            fails += 1
+            first = next((i for i, (x, y) in enumerate(zip(rows, want_rows)) if x != y), min(len(rows), len(want_rows)))
+            print(f"FACE-B MISMATCH seed {seed - 1} bytes={len(big)} bs={fbs} count={count} limit={limit} chunk_mb={os.environ['HYPERGREP_CHUNK_MB']} "
+                  f"gz={path.endswith('.gz')} rc {rc}/{want_rc} rows {len(rows)}/{len(want_rows)} first diff at {first}: "
+                  f"{rows[first:first + 2]} vs {want_rows[first:first + 2]} pats={pats} flags={flags} ids={ids}", flush=True)
+        continue
     try:
         want, nlines = oracle_hits(data, pats, flags, ids, buffer_size=bs)
         got, stats = gpu_scan_buffer(torch, data, pats, flags, ids, buffer_size=bs)
