@@ -432,7 +432,8 @@ extern "C" int hyperscan(char *file_name, const char *const *patterns, const uns
   size_t cap = chunk_bytes();
   const bool one_chunk = !in.compressed() && in.size_hint() && in.size_hint() < cap;
   if (one_chunk) cap = std::max<size_t>(in.size_hint() + 16, 1 << 16);
-  cap = std::max<size_t>(cap, static_cast<size_t>(std::min<uint64_t>(2 * bs1 + 16, static_cast<uint64_t>(1) << 32)));
+  // a chunk must hold a whole piece plus the carry of the previous one — unless the whole file is one chunk anyway
+  if (!one_chunk) cap = std::max<size_t>(cap, static_cast<size_t>(std::min<uint64_t>(2 * bs1 + 16, static_cast<uint64_t>(1) << 32)));
   const int nslots = one_chunk ? 1 : Ctx::kSlots;
   if (hipSetDevice(ctx->device) != hipSuccess || !ensure_buffers(ctx, cap, nslots)) {
     std::fprintf(stderr, "ERROR: Unable to allocate scratch space. Exiting. (device buffers)\n");

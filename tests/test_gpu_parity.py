@@ -670,3 +670,33 @@ def test_expressions_that_can_never_match(torch_cuda):
         got, stats = gpu_scan_buffer(torch_cuda, data, pats, flags, ids, buffer_size=bs)
         assert stats.n_lines == nlines and got == want, bs
     assert {h[1] for h in want} == {0, 3, 4, 5}
+
+
+@pytest.mark.gpu
+def test_maximum_buffer_size(torch_cuda, tmp_path):
+    """buffer_size = INT_MAX (the largest value the reference's int argument takes): pieces are whole lines, the end offset
+    field of the sort key is 31 bits wide; through the device API and through the file API (a small file stays one chunk)."""
+    import hypergrep_amd
+
+    rng = random.Random(52)
+    pats = ["foo", "ba+r", "x=[0-9]+;", "needle_in_haystack", "\\bend$"]
+    flags = [14, 6, 14, 14, 14]
+    ids = [0, 1, 2, 3, 0]
+    lines = [" ".join(rng.choice(["foo", "bar", "baaar", "x=12;", "needle_in_haystack", "end", "lorem", "ipsum"]) for _ in range(rng.randint(0, 9))) for _ in range(4000)]
+    lines[1234] = "z" * 70000 + " foo end"
+    data = ("\n".join(lines) + "\n").encode()
+    big = 2147483647
+    want, nlines = oracle_hits(data, pats, flags, ids, buffer_size=big)
+    got, stats = gpu_scan_buffer(torch_cuda, data, pats, flags, ids, buffer_size=big)
+    assert stats.n_lines == nlines == 4000 and got == want and len(want) > 3000
+    path = tmp_path / "max.log"
+    path.write_bytes(data)
+    want_rc, want_rows, want_batches = oracle_py.scan_file(str(path), pats, flags, ids, buffer_size=big, buffer_count=2)
+    rows, batches = [], []
+
+    def cb(matches, count):
+        batches.append(count)
+        rows.extend((matches[i].line_number, matches[i].id, matches[i].line) for i in range(count))
+
+    rc = hypergrep_amd.scan(str(path), pats, cb, flags=flags, ids=ids, buffer_size=big, buffer_count=2)
+    assert (rc, rows, batches) == (want_rc, want_rows, want_batches) and rc == 0
