@@ -1411,6 +1411,78 @@ __device__ __forceinline__ void always_on_segment1(const AlwaysOnCtx &a, const H
   }
 }
 
+// The same for automata without boundary conditions (`simple`), the bulk of the always-on tier: only the bytes [first, stop)
+// matter (no context byte at `stop`), the text comes a dword at a time, and the per-byte work is a dozen selects.
+template <int NT>  // follow-union tables in use: ceil(nodes / 8)
+__device__ __forceinline__ void always_on_simple(const AlwaysOnCtx &a, const HgPattern &p, uint32_t pi, const hgdev::lds_u32 *tab, uint64_t lo, uint64_t hi,
+                                                 uint64_t line_start, uint64_t bs1, uint32_t rank_lo) {
+  if (lo >= hi) return;
+  const hgdev::lds_u32 *reach = tab + CT_REACH, *fu = tab + CT_FU;
+  uint64_t q = line_start;  // first byte the automaton sees (always_on_segment)
+  if (p.max_len && p.max_len <= HG_ALWAYS_ON_FAST_MAX_LEN) {
+    const uint32_t lead = p.max_len - 1;
+    q = lo > lead ? lo - lead : 0;
+  } else if (lo - line_start >= bs1) {
+    q = line_start + (lo - line_start) / bs1 * bs1;
+  }
+  const uint64_t base = q & ~15ull;
+  const uint32_t first = static_cast<uint32_t>(q - base), own = static_cast<uint32_t>(lo - base), stop = static_cast<uint32_t>(hi - base);
+  const uint32_t span = stop - first;
+  const uint32_t I = p.init_word, acc = p.acc_all;
+  const uint32_t single = p.single ? 1u : 0u;
+  constexpr uint32_t NO_BREAK = 0xFFFFFFFFu;
+  const uint32_t bs1c = bs1 < 0x7FFFFFFFull ? static_cast<uint32_t>(bs1) : 0x7FFFFFFFu;
+  uint32_t nb = NO_BREAK;  // next forced break, relative to base
+  if (q >= line_start) {
+    const uint64_t d = q - line_start, k = d < bs1 ? 0 : d / bs1;
+    const uint64_t at = line_start + k * bs1 + bs1 - base;
+    nb = at < 0x7FFFFFFFull ? static_cast<uint32_t>(at) : NO_BREAK;
+  }
+  // dwords of the text from `base` on; the buffer is readable up to the next multiple of 16 past its end (bytes at or past
+  // `stop` are loaded but never consumed)
+  const uint32_t *t32 = reinterpret_cast<const uint32_t *>(a.text + base);
+  const uint32_t last_dw = static_cast<uint32_t>((((a.nbytes + 15) & ~15ull) - base) >> 2) - 1u;
+  uint32_t S = 0, rank = rank_lo, reported = 0;
+  uint32_t ahead = t32[0];
+#pragma unroll 1
+  for (uint32_t off = 0; off < stop; off += 4) {
+    const uint32_t v = ahead;
+    const uint32_t nd = (off >> 2) + 1u;
+    ahead = t32[nd < last_dw ? nd : last_dw];
+    uint32_t rc[4];
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) rc[i] = reach[(v >> (8 * i)) & 0xFFu];
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+      const uint32_t r = off + i;
+      const uint32_t c = (v >> (8 * i)) & 0xFFu;
+      const bool cons = r - first < span;  // first <= r < stop
+      if (r == nb) {  // a forced break: the automaton starts afresh with this byte
+        S = 0;
+        reported = 0;
+        const uint32_t at = r + bs1c;
+        nb = at < 0x7FFFFFFFu ? at : NO_BREAK;
+      }
+      uint32_t T = I | fu[S & 0xFFu];
+      if (NT > 1) T |= fu[256 + ((S >> 8) & 0xFFu)];
+      if (NT > 2) T |= fu[512 + ((S >> 16) & 0xFFu)];
+      if (NT > 3) T |= fu[768 + (S >> 24)];
+      const uint32_t Sn = c ? (T & rc[i]) : 0u;  // a NUL ends the scanned bytes (or is a skipped leading one): start afresh after it
+      S = cons ? Sn : S;
+      if (cons && (Sn & acc) && !(single & reported)) {
+        reported = 1;  // (a match that ends in an earlier segment is that segment's to report; it also settles this line)
+        if (r >= own) always_on_note(a, pi, base + r + 1, rank);
+      }
+      const bool nl = cons && c == '\n';
+      rank += (nl && r >= own) ? 1u : 0u;
+      S = nl ? 0u : S;
+      reported = nl ? 0u : reported;
+      const uint32_t after = r + 1u + bs1c;
+      nb = nl ? (after < 0x7FFFFFFFu ? after : NO_BREAK) : nb;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void hg_always_on_fast_kernel(HgConfirmArgs a) {
   __shared__ uint32_t s_n;
   __shared__ __attribute__((aligned(16))) uint32_t s_tab[4 * AO_TAB_WORDS];
@@ -1469,7 +1541,12 @@ __global__ __launch_bounds__(256) void hg_always_on_fast_kernel(HgConfirmArgs a)
       const HgPattern &p = a.db.patterns[pi];
       const bool simple = p.simple != 0;
       if (!one_pattern) stage(j);
-      if (simple) always_on_segment1<true>(cx, p, pi, tab, lo, hi, line_start, a.bs1, rank_lo);
+      if (simple) {
+        const uint32_t nt = (p.nnodes + 7u) >> 3;  // wave-uniform
+        if (nt <= 1) always_on_simple<1>(cx, p, pi, tab, lo, hi, line_start, a.bs1, rank_lo);
+        else if (nt == 2) always_on_simple<2>(cx, p, pi, tab, lo, hi, line_start, a.bs1, rank_lo);
+        else always_on_simple<4>(cx, p, pi, tab, lo, hi, line_start, a.bs1, rank_lo);
+      }
       else if (p.nw == 1) always_on_segment1<false>(cx, p, pi, tab, lo, hi, line_start, a.bs1, rank_lo);
       else always_on_segment<2, false>(cx, p, pi, tab, lo, hi, line_start, a.bs1, rank_lo);
     }
