@@ -148,9 +148,13 @@ struct StreamCtx {
                                // tile before it << 10, tile, dword left of the chunk, dword right of it, the chunk} — the drain never re-reads the text
   lds_u32 *cand_count;         // the workgroup's candidate counter
   HgCand *seg;                 // the workgroup's private candidate segment
-  uint32_t seg_cap, fold, wa, wb;
-  uint32_t wc, wmask;          // byte-aligned probing: hash C weights and the window's byte mask (3- or 4-byte windows)
+  uint32_t seg_cap, fold, wa, wb;  // wb: slot weights B in wide mode; with byte-aligned probing the hash C weights (their top byte is zero
+                                   // for 3-byte windows).  The struct travels by value to drain_batch: any larger and it goes through scratch
 };
+
+#if defined(__HIP_DEVICE_COMPILE__)  // (LDS pointers are 4 bytes on the device)
+static_assert(sizeof(StreamCtx) <= 64, "StreamCtx is passed by value to the out-of-line drain routine: beyond 16 dwords it travels through scratch (measured: 1.1 GB of scratch writes per 8 GiB launch, stream pass 20 % slower)");
+#endif
 
 // Chunk `g` of the text with the bytes past the end of the text zeroed.
 __device__ __forceinline__ uint4 load_chunk_checked(const uint4 *__restrict__ text16, uint64_t nbytes, uint64_t g) {
@@ -205,8 +209,8 @@ __device__ __noinline__ void drain_batch(const StreamCtx cx, uint32_t first, uin
       rank = e_lo >> 10;
       cur = load_chunk_checked(cx.text16, cx.nbytes, g);
       nxt = load_dword_checked(cx.text16, cx.nbytes, (g + 1) << 4);
-      const uint32_t l1 = ProbeBytes<LOG2>::template probe16<false>(cx.filter, cx.fold, cx.wa, cx.wc, cur, nxt);
-      const uint32_t wbytes = cx.wmask == 0xFFFFFFFFu ? 4u : 3u;
+      const uint32_t l1 = ProbeBytes<LOG2>::template probe16<false>(cx.filter, cx.fold, cx.wa, cx.wb, cur, nxt);
+      const uint32_t wbytes = (cx.wb >> 24) ? 4u : 3u, wmask = (cx.wb >> 24) ? 0xFFFFFFFFu : 0x00FFFFFFu;
       constexpr uint32_t BYTE_MASK = ((1u << LOG2) - 1u) << 2;
       const uint8_t *text = reinterpret_cast<const uint8_t *>(cx.text16);
       for (uint32_t todo = l1; todo; todo &= todo - 1) {
@@ -224,7 +228,7 @@ __device__ __noinline__ void drain_batch(const StreamCtx cx, uint32_t first, uin
             if (pos + wbytes + b < cx.nbytes) next |= static_cast<uint32_t>(text[pos + wbytes + b]) << (8 * b);
           }
         }
-        const uint32_t f = (wk | cx.fold) & cx.wmask;
+        const uint32_t f = (wk | cx.fold) & wmask;
         const HgSlotInfo info = cx.ext[(hg_dot4(f, cx.wa) & BYTE_MASK) >> 2];
         if (hg_slot_pass(info, f, prev | cx.fold, next | cx.fold, 0xFFFFFFFFu, 0xFFFFFFFFu)) hits |= 1u << k;
       }
@@ -377,7 +381,7 @@ __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, 
     bool any;
     if constexpr (DENSE) {
       const uint32_t nxt = __builtin_amdgcn_update_dpp(after, cur.x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);  // lane 63 keeps `after`
-      any = ProbeBytes<LOG2>::template probe16<true>(cx.filter, cx.fold, cx.wa, cx.wc, cur, nxt) != 0;
+      any = ProbeBytes<LOG2>::template probe16<true>(cx.filter, cx.fold, cx.wa, cx.wb, cur, nxt) != 0;
     } else {
       any = Probe<LOG2, WIDE>::template probe4<true>(cx.filter, cx.fold, cx.wa, cx.wb, cur) != 0;
     }
@@ -497,8 +501,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_S
                                                                   const uint4 *__restrict__ filter16, const uint4 *__restrict__ ext16,
                                                                   uint32_t fold, uint32_t wa, uint32_t wb, HgTileSum *__restrict__ sums,
                                                                   HgCand *__restrict__ cands, uint32_t seg_cap,
-                                                                  uint32_t *__restrict__ seg_count, uint32_t *__restrict__ counters, uint32_t span,
-                                                                  uint32_t wc, uint32_t wmask) {
+                                                                  uint32_t *__restrict__ seg_count, uint32_t *__restrict__ counters, uint32_t span) {
   // LDS, one block so that the filter starts at offset 0 (its byte offsets then fold into the ds_read instructions):
   //   window hash slots (4 B each) | per-wave chunk queues | candidate counter
   constexpr uint32_t FILTER_U4 = (4u << LOG2) / 16, QUEUE_U4 = WG_WAVES * queue_cap(LOG2) * queue_entry_dw(LOG2, DENSE) * 4 / 16;
@@ -522,8 +525,6 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_S
   cx.fold = fold;
   cx.wa = wa;
   cx.wb = wb;
-  cx.wc = wc;
-  cx.wmask = wmask;
   const uint64_t full_tiles = nbytes >> HG_TILE_SHIFT;
   // Tile order.  span == 0: tiles are dealt round-robin over all waves of the grid (the chip streams one contiguous window).
   // span > 0: workgroup b owns the `span` consecutive tiles from tile_begin + b * span, so that the candidates of a segment
@@ -559,7 +560,7 @@ void launch_depth(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
   const uint4 *f = reinterpret_cast<const uint4 *>(a.filter);
   const uint4 *x = reinterpret_cast<const uint4 *>(a.ext);
   hipLaunchKernelGGL((hg_stream_kernel<L, W, B, D>), dim3(grid), dim3(WG_THREADS), 0, stream, t, a.nbytes, a.tile_begin, a.tile_end, f, x, a.db.fold_mask,
-                     a.weights_a, a.weights_b, a.sums, a.cands, a.cand_seg_cap, a.seg_count, a.counters, a.span, a.weights_c, a.db.window_mask);
+                     a.weights_a, a.dense ? a.weights_c : a.weights_b, a.sums, a.cands, a.cand_seg_cap, a.seg_count, a.counters, a.span);
 }
 template <int L, bool W, bool B>
 void launch_one(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
