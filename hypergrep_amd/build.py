@@ -43,6 +43,39 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def _compile_kernels(cmd: list[str]) -> None:
+    """Compile the kernel file with the compiler's per-kernel resource remarks on, keep them next to the library
+    (lib/kernel_resources.json; tests/test_abi.py checks them) and refuse a dword-aligned stream kernel that touches scratch:
+    a by-value argument one field too large once cost 20 % of the pass without failing any test."""
+    import json
+    import re
+
+    proc = subprocess.run(cmd + ["-Rpass-analysis=kernel-resource-usage"], stderr=subprocess.PIPE, text=True)
+    remarks, other = [], []
+    for line in proc.stderr.splitlines():
+        (remarks if "-Rpass-analysis=kernel-resource-usage" in line else other).append(line)
+    if other:
+        print("\n".join(other), file=sys.stderr)
+    if proc.returncode:
+        raise subprocess.CalledProcessError(proc.returncode, cmd)
+    table, name = {}, None
+    for line in remarks:
+        m = re.search(r"remark:\s+(.*?): (.*?) \[-Rpass", line)
+        if not m:
+            continue
+        key, value = m.group(1).strip(), m.group(2).strip()
+        if key == "Function Name":
+            name = value
+            table[name] = {}
+        elif name:
+            table[name][key] = int(value) if value.isdigit() else value
+    with open(os.path.join(LIB_DIR, "kernel_resources.json"), "w", encoding="utf-8") as f:
+        json.dump(table, f, indent=1, sort_keys=True)
+    for kernel, res in table.items():
+        if kernel.startswith("_Z16hg_stream_kernelILi") and "ELb0ELb0E" in kernel and res.get("ScratchSize [bytes/lane]", 0):
+            raise RuntimeError(f"{kernel} uses {res['ScratchSize [bytes/lane]']} bytes of scratch per lane: the streaming hot path must stay in registers")
+
+
 def build(verbose: bool = False, force: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
@@ -62,7 +95,10 @@ def build(verbose: bool = False, force: bool = False) -> str:
                 cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-c", path, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
-            subprocess.check_call(cmd)
+            if src == "hg_kernels.hip":
+                _compile_kernels(cmd)
+            else:
+                subprocess.check_call(cmd)
     if force or _stale(LIB, objs + [os.path.join(CSRC, "exports.map")]):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs + ["-lz", "-ldl", "-Wl,-Bsymbolic", "-Wl,-soname,libhyperscanner.so",
                                                                                 "-Wl,--version-script=" + os.path.join(CSRC, "exports.map")]
