@@ -700,3 +700,49 @@ def test_maximum_buffer_size(torch_cuda, tmp_path):
 
     rc = hypergrep_amd.scan(str(path), pats, cb, flags=flags, ids=ids, buffer_size=big, buffer_count=2)
     assert (rc, rows, batches) == (want_rc, want_rows, want_batches) and rc == 0
+
+
+@pytest.mark.gpu
+def test_concurrent_scans_from_threads(torch_cuda, tmp_path, monkeypatch):
+    """The reference's parallel_grep runs one hyperscan() per file on a thread pool (multiscanner.py:197-209): many
+    concurrent calls in one process, two pattern sets interleaved, files from empty to several ingest chunks — every
+    call must deliver exactly what it delivers alone."""
+    import concurrent.futures
+
+    import hypergrep_amd
+
+    monkeypatch.setenv("HYPERGREP_CHUNK_MB", "1")
+    rng = random.Random(61)
+    sets = [(["ERROR", "status=5[0-9]{2}", "needle_in_haystack"], [14, 14, 14], [0, 1, 2]),
+            (["\\bGET\\b /api", "x=\\d+;", "(?i)warn"], [14, 6, 14], [5, 5, 6])]
+    words = [b"ERROR", b"status=503", b"status=200", b"needle_in_haystack", b"GET /api", b"GETS /api", b"x=12;", b"Warn", b"lorem", b"ipsum", b"dolor"]
+    files = []
+    for i in range(24):
+        nlines = rng.choice([0, 1, 50, 2000, 30000])
+        body = b"".join(b" ".join(rng.choice(words) for _ in range(rng.randint(0, 8))) + b"\n" for _ in range(nlines))
+        path = tmp_path / f"f{i}.log"
+        path.write_bytes(body)
+        files.append(str(path))
+
+    def scan_one(job):
+        path, (pats, flags, ids) = job
+        rows, batches = [], []
+
+        def cb(matches, count):
+            batches.append(count)
+            rows.extend((matches[i].line_number, matches[i].id, matches[i].line) for i in range(count))
+
+        rc = hypergrep_amd.scan(path, pats, cb, flags=flags, ids=ids, buffer_count=rng.choice([1, 16, 64]))
+        return rc, rows, sum(batches)
+
+    jobs = [(f, sets[i % 2]) for i, f in enumerate(files)] + [(f, sets[(i + 1) % 2]) for i, f in enumerate(files)]
+    alone = [scan_one(j) for j in jobs]
+    with concurrent.futures.ThreadPoolExecutor(max_workers=8) as pool:
+        together = list(pool.map(scan_one, jobs))
+    assert together == alone
+    assert all(rc == 0 for rc, _, _ in alone) and sum(n for _, _, n in alone) > 50000
+    # a few of them against the oracle
+    for j in (3, 10, 30):
+        path, (pats, flags, ids) = jobs[j]
+        want_rc, want_rows, _ = oracle_py.scan_file(path, pats, flags, ids)
+        assert (alone[j][0], alone[j][1]) == (want_rc, want_rows)
