@@ -71,6 +71,7 @@ struct HgConfirmArgs {
   uint32_t always_list_cap;               // entries per block of the always-on match list (it reuses `deferred`)
   uint32_t list_spread[HG_CONFIRM_MODES];  // automaton modes: lists per pattern (few patterns: each is spread over several lists)
   uint32_t cand_seg_cap, hit_cap, hit_seg_cap, defer_shard_cap;
+  uint32_t hit_direct;  // 1: a block whose staging segment is full appends to the compact array itself (HitSink)
   uint32_t *counters;
 };
 
@@ -121,6 +122,7 @@ class HgScanner {
   // workspace
   uint64_t cap_tiles_ = 0;
   uint32_t cand_cap_ = 0, hit_cap_ = 0;
+  bool hit_direct_ = false;  // the hits are too unevenly spread for equal per-block segments (HitSink::direct)
   HgTileSum *d_sums_ = nullptr;
   HgTileBase *d_bases_ = nullptr, *d_block_base_ = nullptr, *d_final_ = nullptr;
   HgTileElem *d_agg_ = nullptr;

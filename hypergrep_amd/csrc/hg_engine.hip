@@ -355,6 +355,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       ca.tmp_aux = d_aux_out_;
       ca.cand_seg_cap = sa.cand_seg_cap;
       ca.hit_cap = hit_cap_;
+      ca.hit_direct = hit_direct_ ? 1u : 0u;
       ca.counters = d_counters_;
       if (block_mode) {
         HG_TRY(hipMemsetAsync(d_pflags_, 0, db_->patterns.size() * 4, side), "memset pattern flags");
@@ -474,6 +475,15 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
     }
     if (hit_need || n_raw > hit_cap_) {
       uint64_t want = std::max<uint64_t>((hit_need + hit_need / 4 + 64) * std::max(confirm_blocks, always_blocks), n_raw + n_raw / 4);
+      // equal segments sized for the fullest block: fine while the hits are spread, absurd when one block holds most of them
+      // (every match end of an all-matches expression on one very long line).  Past 64 M records (4 GiB of workspace) or 16
+      // times the hits actually seen, the segments stop growing and full blocks append to the compact array directly.
+      constexpr uint64_t kSegmentLimit = 64ull << 20;
+      const uint64_t by_total = n_raw + n_raw / 4 + 4096;
+      if (want > kSegmentLimit || want > 16 * by_total) {
+        hit_direct_ = true;
+        want = std::min<uint64_t>(want, std::max<uint64_t>(by_total, std::min<uint64_t>(16 * by_total, kSegmentLimit)));
+      }
       want = std::max<uint64_t>(want, static_cast<uint64_t>(hit_cap_) * 2);
       if (want > 0x7FFFFFF0u) {
         err_ = "more than 2^31 hits in one scan call: split the buffer";

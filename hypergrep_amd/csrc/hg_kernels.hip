@@ -739,11 +739,24 @@ struct HitSink {
   HgHitAux *seg_aux;
   uint32_t seg_cap;
   uint32_t *lds_count;
+  // a.hit_direct: a block whose private segment is full appends straight to the compact array (one global atomic per hit).
+  // The engine turns it on when equal segments for every block would have to grow past any sensible size because ONE block
+  // holds most of the hits (all match ends of an all-matches expression on a very long line).
+  HgHit *out_hits;
+  HgHitAux *out_aux;
+  uint32_t *out_count;
+  uint32_t out_cap, direct;
   __device__ __forceinline__ void push(uint64_t line_no, uint32_t id, uint32_t to, uint64_t start, uint32_t len, uint32_t pattern) const {
     const uint32_t slot = atomicAdd(lds_count, 1u);
     if (slot < seg_cap) {
       seg_hits[slot] = HgHit{line_no, id, to};
       seg_aux[slot] = HgHitAux{start, len, pattern};
+    } else if (direct) {
+      const uint32_t at = atomicAdd(out_count, 1u);
+      if (at < out_cap) {
+        out_hits[at] = HgHit{line_no, id, to};
+        out_aux[at] = HgHitAux{start, len, pattern};
+      }
     }
   }
 };
@@ -754,7 +767,7 @@ __device__ __forceinline__ void flush_hits(const HgConfirmArgs &a, uint32_t *lds
     const uint32_t n = *lds_count;
     const uint32_t kept = n < a.hit_seg_cap ? n : a.hit_seg_cap;
     *lds_base = atomicAdd(&a.counters[HG_CNT_HITS], kept);
-    if (n > a.hit_seg_cap) atomicMax(&a.counters[HG_CNT_HIT_NEED], n);
+    if (n > a.hit_seg_cap && !a.hit_direct) atomicMax(&a.counters[HG_CNT_HIT_NEED], n);  // (hits past the segment were dropped: the pass is repeated)
     *lds_count = kept;
   }
   __syncthreads();
@@ -967,7 +980,7 @@ __device__ __forceinline__ void confirm_body(const HgConfirmArgs &a, uint32_t vb
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
   const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
-  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n};
+  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n, a.hits, a.aux, &a.counters[HG_CNT_HITS], a.hit_cap, a.hit_direct};
   // block b walks list b % HG_DEFER_SHARDS with the blocks that share it
   const uint32_t shard = vblock % HG_DEFER_SHARDS, peer = vblock / HG_DEFER_SHARDS, peers = (vgrid + HG_DEFER_SHARDS - 1 - shard) / HG_DEFER_SHARDS;
   const HgDeferred *dlist = a.deferred + (static_cast<uint64_t>(a.list_of_mode[MODE]) * HG_DEFER_SHARDS + shard) * a.defer_shard_cap;
@@ -1018,7 +1031,7 @@ __device__ __forceinline__ void confirm_tables_body(const HgConfirmArgs &a, uint
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
   const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
-  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n};
+  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n, a.hits, a.aux, &a.counters[HG_CNT_HITS], a.hit_cap, a.hit_direct};
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   hgdev::lds_u32 *tab = (hgdev::lds_u32 *)(&s_tab[0]) + wave * CT_WORDS;
   // this block's slice [lo, hi) of the concatenation of the HG_DEFER_SHARDS lists (lane s holds list s)
@@ -1092,7 +1105,7 @@ __global__ __launch_bounds__(256) void hg_always_on_kernel(HgConfirmArgs a, uint
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
   const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
-  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n};
+  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n, a.hits, a.aux, &a.counters[HG_CNT_HITS], a.hit_cap, a.hit_direct};
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
   for (uint64_t tile = a.tile_begin + ((static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6); tile < a.tile_end; tile += waves) {
@@ -1568,7 +1581,7 @@ __global__ __launch_bounds__(256) void hg_always_on_finish_kernel(HgConfirmArgs 
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
   const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
-  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n};
+  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n, a.hits, a.aux, &a.counters[HG_CNT_HITS], a.hit_cap, a.hit_direct};
   const HgDeferred *list = a.deferred + static_cast<uint64_t>(blockIdx.x) * a.always_list_cap;
   const uint32_t n = a.always_count[blockIdx.x];
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
@@ -1606,7 +1619,7 @@ __global__ __launch_bounds__(256) void hg_block_scan_kernel(HgConfirmArgs a, con
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
   const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
-  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n};
+  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n, a.hits, a.aux, &a.counters[HG_CNT_HITS], a.hit_cap, a.hit_direct};
   for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < a.db.npatterns; p += gridDim.x * blockDim.x) {
     const HgPattern &pat = a.db.patterns[p];
     if (pat.tier == 0 && !pattern_flags[p]) continue;

@@ -746,3 +746,24 @@ def test_concurrent_scans_from_threads(torch_cuda, tmp_path, monkeypatch):
         path, (pats, flags, ids) = jobs[j]
         want_rc, want_rows, _ = oracle_py.scan_file(path, pats, flags, ids)
         assert (alone[j][0], alone[j][1]) == (want_rc, want_rows)
+
+
+@pytest.mark.gpu
+def test_skewed_hits_one_long_line_all_matches(torch_cuda):
+    """All-matches expressions (no SINGLEMATCH) on one very long line: every occurrence of the required literal re-reports
+    every match end of the line, so ONE confirm block stages millions of raw hits while the others stage none.  Equal
+    per-block segments sized for the fullest block would need > 2^31 records (found by tools/fuzz_gpu.py: the call failed);
+    full blocks now append to the compact array directly."""
+    rng = random.Random(71)
+    filler = "".join(rng.choice("abcx01 ._-") for _ in range(60000))
+    long_line = "".join(filler[i:i + 1200] + " needle" for i in range(0, 60000, 1200))
+    lines = [" ".join(rng.choice(["needle", "foo", "x=1", "lorem"]) for _ in range(rng.randint(0, 8))) for _ in range(2000)]
+    lines[777] = long_line
+    data = ("\n".join(lines) + "\n").encode()
+    pats = ["needle.{2,}", "aa[a-z]", "foo"]
+    flags = [6, 6, 14]
+    ids = [0, 1, 2]
+    want, nlines = oracle_hits(data, pats, flags, ids)
+    got, stats = gpu_scan_buffer(torch_cuda, data, pats, flags, ids)
+    assert stats.n_lines == nlines and got == want
+    assert len(want) > 50000 and stats.n_raw_hits > 1000000

@@ -15,6 +15,33 @@ import oracle_py  # noqa: E402
 import regex_gen  # noqa: E402
 from test_gpu_parity import gpu_scan_buffer, oracle_hits  # noqa: E402
 
+def rich_pattern(rng):
+    """Constructs beyond regex_gen's core set (both engines accept them): inline flags, POSIX classes, hex escapes, lazy and
+    larger counted repeats, \\A \\z \\Z, \\Q...\\E."""
+    parts = []
+    for _ in range(rng.randint(1, 5)):
+        r = rng.random()
+        if r < 0.25:
+            parts.append(regex_gen.random_pattern(rng))
+        elif r < 0.35:
+            parts.append("(?i:" + "".join(rng.choice("abcxyz") for _ in range(rng.randint(1, 4))) + ")")
+        elif r < 0.45:
+            parts.append(rng.choice(["[[:alpha:]]", "[[:digit:]]", "[[:space:]]", "[[:alnum:]_]", "[[:punct:]]"]) + rng.choice(["", "+", "*", "?", "{2}"]))
+        elif r < 0.55:
+            parts.append(rng.choice(["\\x61", "\\x{62}", "\\x30", "\\t", "\\x20"]))
+        elif r < 0.65:
+            parts.append(rng.choice("abcxyz01_") + rng.choice(["+?", "*?", "??", "{2,5}?", "{3,9}", "{6,}"]))
+        elif r < 0.72:
+            parts.append(rng.choice(["\\A", "\\z", "\\Z", "\\b", "\\B"]))
+        elif r < 0.80:
+            parts.append("\\Q" + "".join(rng.choice("ab.=-_ 0") for _ in range(rng.randint(1, 5))) + "\\E")
+        elif r < 0.90:
+            parts.append("(?:" + "|".join("".join(rng.choice("abcxyz019_-= ") for _ in range(rng.randint(1, 7))).replace("-", "\\-") for _ in range(rng.randint(2, 4))) + ")")
+        else:
+            parts.append("".join(rng.choice("abcxyz019_= ") for _ in range(rng.randint(3, 12))))
+    return "".join(parts)
+
+
 def regex_gen_escape(word):
     return "".join("\\" + c if c in ".-=" else c for c in word)
 
@@ -27,7 +54,7 @@ last_print = t0
 while time.time() - t0 < budget:
     rng = random.Random(seed)
     seed += 1
-    kind = rng.choice(["random", "random", "anchored", "mixed", "keywords", "keywords"])
+    kind = rng.choice(["random", "random", "anchored", "mixed", "keywords", "keywords", "rich", "rich"])
     if kind == "keywords":  # word lists: byte-aligned probing, 3-byte windows, short and long literals side by side
         lo, hi = rng.choice([(3, 3), (3, 5), (4, 6), (3, 9), (5, 12)])
         n = rng.choice([2, 8, 40, 300])
@@ -35,6 +62,9 @@ while time.time() - t0 < budget:
         pats = [regex_gen_escape(w) for w in pats]
         if rng.random() < 0.5:
             pats += [regex_gen.random_pattern(rng) for _ in range(rng.randint(1, 2))]
+        samplers = []
+    elif kind == "rich":
+        pats = [rich_pattern(rng) for _ in range(rng.randint(1, 5))]
         samplers = []
     elif kind == "random":
         k = rng.randint(1, 6)
