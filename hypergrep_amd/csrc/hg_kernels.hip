@@ -741,21 +741,18 @@ struct HitSink {
   uint32_t *lds_count;
   // a.hit_direct: a block whose private segment is full appends straight to the compact array (one global atomic per hit).
   // The engine turns it on when equal segments for every block would have to grow past any sensible size because ONE block
-  // holds most of the hits (all match ends of an all-matches expression on a very long line).
-  HgHit *out_hits;
-  HgHitAux *out_aux;
-  uint32_t *out_count;
-  uint32_t out_cap, direct;
-  __device__ __forceinline__ void push(uint64_t line_no, uint32_t id, uint32_t to, uint64_t start, uint32_t len, uint32_t pattern) const {
+  // holds most of the hits (all match ends of an all-matches expression on a very long line).  (The compact array's
+  // fields are read from the kernel arguments at the call, not kept here: a larger struct went through scratch.)
+  __device__ __forceinline__ void push(const HgConfirmArgs &a, uint64_t line_no, uint32_t id, uint32_t to, uint64_t start, uint32_t len, uint32_t pattern) const {
     const uint32_t slot = atomicAdd(lds_count, 1u);
     if (slot < seg_cap) {
       seg_hits[slot] = HgHit{line_no, id, to};
       seg_aux[slot] = HgHitAux{start, len, pattern};
-    } else if (direct) {
-      const uint32_t at = atomicAdd(out_count, 1u);
-      if (at < out_cap) {
-        out_hits[at] = HgHit{line_no, id, to};
-        out_aux[at] = HgHitAux{start, len, pattern};
+    } else if (a.hit_direct) {
+      const uint32_t at = atomicAdd(&a.counters[HG_CNT_HITS], 1u);
+      if (at < a.hit_cap) {
+        a.hits[at] = HgHit{line_no, id, to};
+        a.aux[at] = HgHitAux{start, len, pattern};
       }
     }
   }
@@ -980,7 +977,7 @@ __device__ __forceinline__ void confirm_body(const HgConfirmArgs &a, uint32_t vb
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
   const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
-  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n, a.hits, a.aux, &a.counters[HG_CNT_HITS], a.hit_cap, a.hit_direct};
+  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n};
   // block b walks list b % HG_DEFER_SHARDS with the blocks that share it
   const uint32_t shard = vblock % HG_DEFER_SHARDS, peer = vblock / HG_DEFER_SHARDS, peers = (vgrid + HG_DEFER_SHARDS - 1 - shard) / HG_DEFER_SHARDS;
   const HgDeferred *dlist = a.deferred + (static_cast<uint64_t>(a.list_of_mode[MODE]) * HG_DEFER_SHARDS + shard) * a.defer_shard_cap;
@@ -991,7 +988,7 @@ __device__ __forceinline__ void confirm_body(const HgConfirmArgs &a, uint32_t vb
     const uint32_t pattern = d.pattern & (HG_MAX_PATTERNS - 1u);
     const HgPattern &p = a.db.patterns[pattern];
     const uint32_t id = p.id;
-    auto emit = [&](uint64_t line_no, uint32_t to, uint64_t start, uint32_t len) { sink.push(line_no, id, to, start, len, pattern); };
+    auto emit = [&](uint64_t line_no, uint32_t to, uint64_t start, uint32_t len) { sink.push(a, line_no, id, to, start, len, pattern); };
     if (MODE == 0) hgdev::confirm_literal(a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, d.rank, d.pos - (d.pattern >> 24), p.max_len, emit);
     else hg_confirm(a.db, a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, pattern, d.rank, emit);
   }
@@ -1031,7 +1028,7 @@ __device__ __forceinline__ void confirm_tables_body(const HgConfirmArgs &a, uint
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
   const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
-  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n, a.hits, a.aux, &a.counters[HG_CNT_HITS], a.hit_cap, a.hit_direct};
+  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n};
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   hgdev::lds_u32 *tab = (hgdev::lds_u32 *)(&s_tab[0]) + wave * CT_WORDS;
   // this block's slice [lo, hi) of the concatenation of the HG_DEFER_SHARDS lists (lane s holds list s)
@@ -1068,7 +1065,7 @@ __device__ __forceinline__ void confirm_tables_body(const HgConfirmArgs &a, uint
       __builtin_amdgcn_wave_barrier();
       if (mine) {
         const uint32_t id = p.id;
-        auto emit = [&](uint64_t line_no, uint32_t to, uint64_t start_, uint32_t len) { sink.push(line_no, id, to, start_, len, pat); };
+        auto emit = [&](uint64_t line_no, uint32_t to, uint64_t start_, uint32_t len) { sink.push(a, line_no, id, to, start_, len, pat); };
         if (MODE == 1) {
           hgdev::confirm_simple(a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, d.rank, p.init_word, p.acc_all, tab + CT_REACH, tab + CT_FOLLOW, emit);
         } else if (nw == 1) {
@@ -1105,7 +1102,7 @@ __global__ __launch_bounds__(256) void hg_always_on_kernel(HgConfirmArgs a, uint
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
   const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
-  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n, a.hits, a.aux, &a.counters[HG_CNT_HITS], a.hit_cap, a.hit_direct};
+  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n};
   const uint32_t lane = threadIdx.x & 63u;
   const uint64_t waves = (static_cast<uint64_t>(gridDim.x) * blockDim.x) >> 6;
   for (uint64_t tile = a.tile_begin + ((static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6); tile < a.tile_end; tile += waves) {
@@ -1120,7 +1117,7 @@ __global__ __launch_bounds__(256) void hg_always_on_kernel(HgConfirmArgs a, uint
       if (starts)
         hg_scan_line_always_on(a.db, a.text, a.nbytes, a.sums, a.bases, a.bs1, s, rank, first, last,
                                [&](uint32_t pi, uint64_t line_no, uint32_t to, uint64_t start, uint32_t len) {
-                                 sink.push(line_no, a.db.patterns[pi].id, to, start, len, pi);
+                                 sink.push(a, line_no, a.db.patterns[pi].id, to, start, len, pi);
                                });
       rank += a.text[s] == '\n';
     }
@@ -1581,7 +1578,7 @@ __global__ __launch_bounds__(256) void hg_always_on_finish_kernel(HgConfirmArgs 
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
   const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
-  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n, a.hits, a.aux, &a.counters[HG_CNT_HITS], a.hit_cap, a.hit_direct};
+  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n};
   const HgDeferred *list = a.deferred + static_cast<uint64_t>(blockIdx.x) * a.always_list_cap;
   const uint32_t n = a.always_count[blockIdx.x];
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
@@ -1596,7 +1593,7 @@ __global__ __launch_bounds__(256) void hg_always_on_finish_kernel(HgConfirmArgs 
       if (blocked) continue;
     }
     const uint64_t z = a.text[pos] == '\n' ? end : hgdev::scanned_end(a.text, end, pv.limit);
-    sink.push(pv.line_no, a.db.patterns[d.pattern].id, static_cast<uint32_t>(end - pv.a), pv.a, static_cast<uint32_t>(z - pv.a), d.pattern);
+    sink.push(a, pv.line_no, a.db.patterns[d.pattern].id, static_cast<uint32_t>(end - pv.a), pv.a, static_cast<uint32_t>(z - pv.a), d.pattern);
   }
   flush_hits(a, &s_n, &s_base);
 }
@@ -1619,12 +1616,12 @@ __global__ __launch_bounds__(256) void hg_block_scan_kernel(HgConfirmArgs a, con
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
   const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
-  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n, a.hits, a.aux, &a.counters[HG_CNT_HITS], a.hit_cap, a.hit_direct};
+  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n};
   for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < a.db.npatterns; p += gridDim.x * blockDim.x) {
     const HgPattern &pat = a.db.patterns[p];
     if (pat.tier == 0 && !pattern_flags[p]) continue;
     hg_nfa_scan(a.db.pool, pat, a.text, a.nbytes,
-                [&](uint32_t to) { sink.push(0, pat.id, to, 0, static_cast<uint32_t>(a.nbytes), p); });
+                [&](uint32_t to) { sink.push(a, 0, pat.id, to, 0, static_cast<uint32_t>(a.nbytes), p); });
   }
   flush_hits(a, &s_n, &s_base);
 }
