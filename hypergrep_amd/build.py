@@ -72,7 +72,7 @@ def _compile_kernels(cmd: list[str]) -> None:
     with open(os.path.join(LIB_DIR, "kernel_resources.json"), "w", encoding="utf-8") as f:
         json.dump(table, f, indent=1, sort_keys=True)
     for kernel, res in table.items():
-        if kernel.startswith("_Z16hg_stream_kernelILi") and "ELb0ELb0E" in kernel and res.get("ScratchSize [bytes/lane]", 0):
+        if kernel.startswith("_Z16hg_stream_kernelILi") and "ELb0ELi0E" in kernel and res.get("ScratchSize [bytes/lane]", 0):
             raise RuntimeError(f"{kernel} uses {res['ScratchSize [bytes/lane]']} bytes of scratch per lane: the streaming hot path must stay in registers")
 
 

@@ -931,14 +931,15 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
     }
     // One window per residue mod 4 (the stream pass probes dword-aligned windows) — or, with byte-aligned probing
     // (db.dense), ONE window per literal at any offset.
-    for (uint32_t res = 0; res < (db.dense ? 1u : 4u); res++) {
+    const uint32_t step = db.dense ? db.dense : 4u;  // the stream pass probes a window every `step` bytes: one window per residue mod step
+    for (uint32_t res = 0; res < step; res++) {
       // The stream kernel compares the window in its hot path and the 12-byte neighbourhood [o-4, o+8) in the second level.
       // With sample statistics: take the offset whose window dword is rarest in the sample.  Without:
       // the offset whose known bytes are the most selective by a static byte-frequency table.
       int best = -1;
       long best_cost = 0;
       int best_sel = -1;
-      for (uint32_t o = res; o + wbytes <= fct.len; o += db.dense ? 1 : 4) {
+      for (uint32_t o = res; o + wbytes <= fct.len; o += step) {
         uint32_t v = 0;
         std::memcpy(&v, fct.lit + o, wbytes);
         v = (v | fold) & wmask;
@@ -1415,7 +1416,13 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
   }
   int rc = -5;
   if (shortest != SIZE_MAX && !std::getenv("HG_NO_BYTE_WINDOWS")) {
-    rc = assign(static_cast<uint32_t>(shortest), 1, HG_WINDOW_BYTES);
+    // every literal of the set has at least 5 bytes: a window on both residues mod 2 fits, half the probes
+    size_t set_shortest = SIZE_MAX;
+    for (unsigned i = 0; i < n; i++)
+      if (!covers[i].lits.empty() && min_len(covers[i].lits) >= shortest) set_shortest = std::min(set_shortest, min_len(covers[i].lits));
+    const uint32_t step = set_shortest >= HG_WINDOW_BYTES + 1 ? 2u : 1u;
+    rc = assign(static_cast<uint32_t>(shortest), step, HG_WINDOW_BYTES);
+    if (rc == -5 && step == 2) rc = assign(static_cast<uint32_t>(shortest), 1, HG_WINDOW_BYTES);  // (one window per literal instead of two)
     // too many 3-byte literals to enumerate the byte after each: every window shrinks to 3 bytes instead
     if (rc == -5 && shortest < HG_WINDOW_BYTES) rc = assign(static_cast<uint32_t>(shortest), 1, HG_WINDOW_BYTES - 1);
     if (rc == -5 && shortest < HG_WINDOW_BYTES) rc = assign(HG_WINDOW_BYTES, 1, HG_WINDOW_BYTES);  // without the short literals
@@ -1433,7 +1440,7 @@ int hgc_tune(HgDb *db, const uint8_t *sample, size_t nbytes, std::string *err) {
   if (!db || (!sample && nbytes)) return -1;
   SampleStats st;
   const uint32_t fold = db->fold_mask;
-  for (size_t p = 0; p + 4 <= nbytes; p += db->dense ? 1 : 4) {
+  for (size_t p = 0; p + 4 <= nbytes; p += db->dense ? db->dense : 4) {
     uint32_t w, nx = 0;
     std::memcpy(&w, sample + p, 4);
     if (p + 8 <= nbytes) std::memcpy(&nx, sample + p + 4, 4);

@@ -24,7 +24,8 @@ struct HgDb {
   uint32_t window_bytes = HG_WINDOW_BYTES;  // bytes of a window: 4, or 3 with byte-aligned probing when 3-byte literals are too many to enumerate
   uint32_t window_mask = HG_WINDOW_MASK;
   uint32_t weights_c = HG_HASH_WEIGHTS;     // hash C weights (the top weight is zero for 3-byte windows: that byte is not part of the window)
-  uint32_t dense = 0;                // 1: the stream pass probes a window at every byte offset, one window per literal (sets with short literals)
+  uint32_t dense = 0;                // byte-aligned probing (sets with short literals): the stream pass probes a window every `dense` bytes
+                                     // (1: one window per literal; 2: literals of >= 5 bytes, a window on both residues mod 2); 0: dword-aligned
   uint32_t weights_a = HG_SLOT_WEIGHT_CHOICES[0][0], weights_b = HG_SLOT_WEIGHT_CHOICES[0][1];
   std::vector<HgSlotInfo> ext;       // per filter slot: the window values in it and their neighbour-dword conditions (second-level check)
   std::vector<uint32_t> slow;        // indices of tier-1 (always-on) patterns, the nslow_fast bounded ones with <= 2 state words first

@@ -102,7 +102,7 @@ struct Probe {
 // Byte-aligned probing (pattern sets with required literals shorter than HG_FAST_MIN_FACTOR, db.dense): every byte of the
 // lane's 16 is the start of a window, `nxt` = the dword after the chunk.  One window per literal instead of one per
 // residue; four times the probes of the dword-aligned filter.
-template <int LOG2>
+template <int LOG2, int STEP>  // STEP: a window starts at every byte (1) or every second byte (2: sets whose literals all have >= 5 bytes)
 struct ProbeBytes {
   static constexpr uint32_t BYTE_MASK = ((1u << LOG2) - 1u) << 2;
   // ANY_ONLY: non-zero iff any of the 16 windows matched; else bit k = the window that starts at byte k matched
@@ -115,11 +115,11 @@ struct ProbeBytes {
       uint32_t w[4], t[4];
       w[0] = d[j];
 #pragma unroll
-      for (int k = 1; k < 4; k++) w[k] = __builtin_amdgcn_alignbyte(d[j + 1], d[j], k);
+      for (int k = STEP; k < 4; k += STEP) w[k] = __builtin_amdgcn_alignbyte(d[j + 1], d[j], k);
 #pragma unroll
-      for (int k = 0; k < 4; k++) t[k] = Probe<LOG2, false>::at(filter, hg_dot4(w[k], wa) & BYTE_MASK);
+      for (int k = 0; k < 4; k += STEP) t[k] = Probe<LOG2, false>::at(filter, hg_dot4(w[k], wa) & BYTE_MASK);
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
+      for (int k = 0; k < 4; k += STEP) {
         const bool m = hg_slot_match(t[k], hg_dot4(w[k], wc));  // (3-byte windows: both weight vectors end in zero)
         if (ANY_ONLY) bits |= m ? 1u : 0u;
         else bits |= m ? (1u << (j * 4 + k)) : 0u;
@@ -192,7 +192,7 @@ __device__ __forceinline__ uint32_t dense_window(uint4 cur, uint32_t nxt, uint32
 // ago), repeats the first level per window, applies the second level (the slot's neighbour conditions) and appends the
 // survivors to the workgroup's candidate segment.  The queue outlives tiles, so batches are full (64 entries) except the
 // last one of the kernel.
-template <int LOG2, bool WIDE, bool DENSE>
+template <int LOG2, bool WIDE, int DENSE>  // DENSE: 0 dword-aligned windows, else the byte step of byte-aligned probing
 __device__ __noinline__ void drain_batch(const StreamCtx cx, uint32_t first, uint32_t n, uint32_t lane) {
   const bool active = lane < n;
   uint32_t hits = 0, rank = 0;
@@ -209,7 +209,7 @@ __device__ __noinline__ void drain_batch(const StreamCtx cx, uint32_t first, uin
       rank = e_lo >> 10;
       cur = load_chunk_checked(cx.text16, cx.nbytes, g);
       nxt = load_dword_checked(cx.text16, cx.nbytes, (g + 1) << 4);
-      const uint32_t l1 = ProbeBytes<LOG2>::template probe16<false>(cx.filter, cx.fold, cx.wa, cx.wb, cur, nxt);
+      const uint32_t l1 = ProbeBytes<LOG2, DENSE ? DENSE : 1>::template probe16<false>(cx.filter, cx.fold, cx.wa, cx.wb, cur, nxt);
       const uint32_t wbytes = (cx.wb >> 24) ? 4u : 3u, wmask = (cx.wb >> 24) ? 0xFFFFFFFFu : 0x00FFFFFFu;
       constexpr uint32_t BYTE_MASK = ((1u << LOG2) - 1u) << 2;
       const uint8_t *text = reinterpret_cast<const uint8_t *>(cx.text16);
@@ -331,7 +331,7 @@ __device__ __noinline__ void drain_batch(const StreamCtx cx, uint32_t first, uin
 
 // One tile.  FULL: the tile lies entirely inside the text (no bounds checks on the hot path).
 // qn: entries in the wave's queue (wave-uniform, carried from tile to tile).
-template <int LOG2, bool WIDE, bool DENSE, bool FULL, int DEPTH>
+template <int LOG2, bool WIDE, int DENSE, bool FULL, int DEPTH>
 __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, HgTileSum *__restrict__ sums, uint32_t lane, uint32_t &qn) {
   const uint4 *__restrict__ text16 = cx.text16;
   const uint64_t nbytes = cx.nbytes;
@@ -381,7 +381,7 @@ __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, 
     bool any;
     if constexpr (DENSE) {
       const uint32_t nxt = __builtin_amdgcn_update_dpp(after, cur.x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);  // lane 63 keeps `after`
-      any = ProbeBytes<LOG2>::template probe16<true>(cx.filter, cx.fold, cx.wa, cx.wb, cur, nxt) != 0;
+      any = ProbeBytes<LOG2, DENSE ? DENSE : 1>::template probe16<true>(cx.filter, cx.fold, cx.wa, cx.wb, cur, nxt) != 0;
     } else {
       any = Probe<LOG2, WIDE>::template probe4<true>(cx.filter, cx.fold, cx.wa, cx.wb, cur) != 0;
     }
@@ -496,7 +496,7 @@ __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, 
 #endif
 // DEPTH: 16-byte loads in flight per lane.  With non-temporal loads three is best for both kinds of launch (before, a launch
 // that had three workgroups per CU to itself did better with one: deeper prefetch thrashed the L2).
-template <int LOG2, bool WIDE, bool DENSE, int DEPTH>
+template <int LOG2, bool WIDE, int DENSE, int DEPTH>
 __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_STREAM_WAVES, 8))) void hg_stream_kernel(const uint4 *__restrict__ text16, uint64_t nbytes, uint64_t tile_begin, uint64_t tile_end,
                                                                   const uint4 *__restrict__ filter16, const uint4 *__restrict__ ext16,
                                                                   uint32_t fold, uint32_t wa, uint32_t wb, HgTileSum *__restrict__ sums,
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_S
 
 // Host-side launcher: picks the instantiation for the database's filter size / mode.
 namespace {
-template <int L, bool W, bool B, int D>
+template <int L, bool W, int B, int D>
 void launch_depth(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
   const uint4 *t = reinterpret_cast<const uint4 *>(a.text);
   const uint4 *f = reinterpret_cast<const uint4 *>(a.filter);
@@ -562,13 +562,13 @@ void launch_depth(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
   hipLaunchKernelGGL((hg_stream_kernel<L, W, B, D>), dim3(grid), dim3(WG_THREADS), 0, stream, t, a.nbytes, a.tile_begin, a.tile_end, f, x, a.db.fold_mask,
                      a.weights_a, a.dense ? a.weights_c : a.weights_b, a.sums, a.cands, a.cand_seg_cap, a.seg_count, a.counters, a.span);
 }
-template <int L, bool W, bool B>
+template <int L, bool W, int B>
 void launch_one(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
   // filters up to 16 KiB leave room for three workgroups per CU: a launch that has the chip to itself prefetches one chunk ahead
   if (!W && !B && L <= 12 && a.alone) launch_depth<L, W, B, (!W && !B && L <= 12) ? HG_DEPTH_ALONE : HG_DEPTH_SHARED>(a, grid, stream);
   else launch_depth<L, W, B, HG_DEPTH_SHARED>(a, grid, stream);
 }
-template <int L, bool W, bool B>
+template <int L, bool W, int B>
 int blocks_one() {
   int n = 0;
   (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (hg_stream_kernel<L, W, B, HG_DEPTH_SHARED>), WG_THREADS, 0);
@@ -578,50 +578,70 @@ int blocks_one() {
 void hg_launch_stream(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
   if (a.filter_wide) {
     switch (a.filter_log2) {
-      case 13: launch_one<13, true, false>(a, grid, stream); break;
-      case 14: launch_one<14, true, false>(a, grid, stream); break;
-      case 15: launch_one<15, true, false>(a, grid, stream); break;
+      case 13: launch_one<13, true, 0>(a, grid, stream); break;
+      case 14: launch_one<14, true, 0>(a, grid, stream); break;
+      case 15: launch_one<15, true, 0>(a, grid, stream); break;
       default: break;
     }
     return;
   }
-  if (a.dense) {  // byte-aligned probing
+  if (a.dense == 1) {  // byte-aligned probing, a window at every byte
     switch (a.filter_log2) {
-      case 11: launch_one<11, false, true>(a, grid, stream); break;
-      case 12: launch_one<12, false, true>(a, grid, stream); break;
-      case 13: launch_one<13, false, true>(a, grid, stream); break;
-      case 14: launch_one<14, false, true>(a, grid, stream); break;
-      case 15: launch_one<15, false, true>(a, grid, stream); break;
+      case 11: launch_one<11, false, 1>(a, grid, stream); break;
+      case 12: launch_one<12, false, 1>(a, grid, stream); break;
+      case 13: launch_one<13, false, 1>(a, grid, stream); break;
+      case 14: launch_one<14, false, 1>(a, grid, stream); break;
+      case 15: launch_one<15, false, 1>(a, grid, stream); break;
+      default: break;
+    }
+    return;
+  }
+  if (a.dense == 2) {  // ... at every second byte
+    switch (a.filter_log2) {
+      case 11: launch_one<11, false, 2>(a, grid, stream); break;
+      case 12: launch_one<12, false, 2>(a, grid, stream); break;
+      case 13: launch_one<13, false, 2>(a, grid, stream); break;
+      case 14: launch_one<14, false, 2>(a, grid, stream); break;
+      case 15: launch_one<15, false, 2>(a, grid, stream); break;
       default: break;
     }
     return;
   }
   switch (a.filter_log2) {
-    case 11: launch_one<11, false, false>(a, grid, stream); break;
-    case 12: launch_one<12, false, false>(a, grid, stream); break;
-    case 13: launch_one<13, false, false>(a, grid, stream); break;
-    case 14: launch_one<14, false, false>(a, grid, stream); break;
-    case 15: launch_one<15, false, false>(a, grid, stream); break;
+    case 11: launch_one<11, false, 0>(a, grid, stream); break;
+    case 12: launch_one<12, false, 0>(a, grid, stream); break;
+    case 13: launch_one<13, false, 0>(a, grid, stream); break;
+    case 14: launch_one<14, false, 0>(a, grid, stream); break;
+    case 15: launch_one<15, false, 0>(a, grid, stream); break;
     default: break;
   }
 }
 int hg_stream_blocks_per_cu(uint32_t filter_log2, uint32_t filter_wide, uint32_t dense) {
-  if (filter_wide) return filter_log2 == 13 ? blocks_one<13, true, false>() : (filter_log2 == 14 ? blocks_one<14, true, false>() : blocks_one<15, true, false>());
-  if (dense) {
+  if (filter_wide) return filter_log2 == 13 ? blocks_one<13, true, 0>() : (filter_log2 == 14 ? blocks_one<14, true, 0>() : blocks_one<15, true, 0>());
+  if (dense == 1) {
     switch (filter_log2) {
-      case 11: return blocks_one<11, false, true>();
-      case 12: return blocks_one<12, false, true>();
-      case 13: return blocks_one<13, false, true>();
-      case 14: return blocks_one<14, false, true>();
-      default: return blocks_one<15, false, true>();
+      case 11: return blocks_one<11, false, 1>();
+      case 12: return blocks_one<12, false, 1>();
+      case 13: return blocks_one<13, false, 1>();
+      case 14: return blocks_one<14, false, 1>();
+      default: return blocks_one<15, false, 1>();
+    }
+  }
+  if (dense == 2) {
+    switch (filter_log2) {
+      case 11: return blocks_one<11, false, 2>();
+      case 12: return blocks_one<12, false, 2>();
+      case 13: return blocks_one<13, false, 2>();
+      case 14: return blocks_one<14, false, 2>();
+      default: return blocks_one<15, false, 2>();
     }
   }
   switch (filter_log2) {
-    case 11: return blocks_one<11, false, false>();
-    case 12: return blocks_one<12, false, false>();
-    case 13: return blocks_one<13, false, false>();
-    case 14: return blocks_one<14, false, false>();
-    default: return blocks_one<15, false, false>();
+    case 11: return blocks_one<11, false, 0>();
+    case 12: return blocks_one<12, false, 0>();
+    case 13: return blocks_one<13, false, 0>();
+    case 14: return blocks_one<14, false, 0>();
+    default: return blocks_one<15, false, 0>();
   }
 }
 

@@ -154,7 +154,8 @@ long hgsim_scan(void *h, const uint8_t *data, uint64_t nbytes, int buffer_size, 
   for (uint64_t t = 0; t < ntiles; t++) {
     uint64_t base = t * HG_TILE_BYTES;
     HgTileSum s{0, HG_NONE32, HG_NONE32, 0};
-    const uint32_t step = db->dense ? 1 : 4;  // byte-aligned probing: a window starts at every byte
+    const uint32_t step = 1;  // newlines are counted byte by byte; windows are probed every `probe_step` bytes
+    const uint32_t probe_step = db->dense ? db->dense : 4;
     for (uint32_t d = 0; d < HG_TILE_BYTES / step; d++) {
       uint64_t pos = base + static_cast<uint64_t>(d) * step;
       if (pos >= nbytes) break;
@@ -163,7 +164,7 @@ long hgsim_scan(void *h, const uint8_t *data, uint64_t nbytes, int buffer_size, 
       std::memcpy(&w, data + pos, avail);  // bytes past the end read as zero, as the kernel masks them
       uint32_t rank_here = s.nl_count;
       uint32_t m = hg_newline_mask(w);
-      if (db->dense) m &= 0x80u;  // only the byte at pos itself
+      m &= 0x80u;  // only the byte at pos itself
       if (m) {
         for (uint32_t b = 0; b < 4; b++)
           if (m >> (8 * b + 7) & 1) {
@@ -172,6 +173,7 @@ long hgsim_scan(void *h, const uint8_t *data, uint64_t nbytes, int buffer_size, 
           }
         s.nl_count += hg_popc(m);
       }
+      if (pos % probe_step) continue;  // windows start every probe_step bytes (absolute offsets: chunks are 16-byte aligned)
       const uint32_t folded = (w | v.fold_mask) & db->window_mask, byte_mask = ((1u << db->filter_log2) - 1u) << 2;
       // bytes outside the text read as zero, like the kernel's masked tail
       auto dword_at = [&](int64_t p) -> uint32_t {

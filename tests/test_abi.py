@@ -113,10 +113,10 @@ def test_streaming_kernels_stay_in_registers():
         pytest.skip("library built by an older build.py (no kernel_resources.json)")
     table = json.load(open(path, encoding="utf-8"))
     stream = {k: v for k, v in table.items() if k.startswith("_Z16hg_stream_kernelILi")}
-    assert len(stream) >= 13
+    assert len(stream) >= 18 and sum(1 for k in stream if "ELb0ELi0E" in k) == 5
     for name, res in stream.items():
         log2 = int(re.match(r"_Z16hg_stream_kernelILi(\d+)E", name).group(1))
-        byte_aligned = "ELb0ELb1E" in name
+        byte_aligned = "ELb0ELi1E" in name or "ELb0ELi2E" in name
         if byte_aligned:  # sixteen probes per chunk: a handful of spilled registers in the drain path is tolerated
             assert res["VGPRs Spill"] <= 8 and res["ScratchSize [bytes/lane]"] <= 64, (name, res)
         else:

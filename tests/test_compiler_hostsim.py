@@ -56,14 +56,18 @@ def test_tiers_and_factors():
     assert info["nslow"] == 1 and info["fold_mask"] == 0x20202020
     assert info["nfactors"] >= 5 and info["nwindows"] == 4 * info["nfactors"]
     assert db.selfcheck()["byte_windows"] == 0
-    # a 6-byte literal joins: the whole set switches to byte-aligned probing, one window per literal
+    # a 6-byte literal joins: the whole set switches to byte-aligned probing; every literal has >= 5 bytes, so a window
+    # starts at every SECOND byte and each literal gets one window per residue mod 2
     db = hgsim_py.Db(["foobar"] + long_ones)
     assert db.ok(), db.error
     assert [db.tier(i) for i in range(6)] == [0, 0, 0, 1, 0, 0]
     info = db.info()
-    assert info["nslow"] == 1 and info["nwindows"] == info["nfactors"]
+    assert info["nslow"] == 1 and info["nwindows"] == 2 * info["nfactors"]
     check = db.selfcheck()
-    assert check["byte_windows"] == 1 and check["violations"] == 0
+    assert check["byte_windows"] == 2 and check["violations"] == 0
+    # a 4-byte literal: a window at every byte, one window per literal
+    db = hgsim_py.Db(["fail"] + long_ones)
+    assert db.ok() and db.selfcheck()["byte_windows"] == 1 and db.info()["nwindows"] == db.info()["nfactors"]
     # 3-byte literals: the byte after the literal is enumerated (256 windows, 128 distinct under case folding)
     db = hgsim_py.Db(["foo", "barbaz"])
     assert db.ok(), db.error
@@ -120,6 +124,39 @@ def test_expressions_that_can_never_match():
     want, _ = oracle_hits(data, pats, flags, ids)
     got, _ = db.scan(data)
     assert sorted(got) == want and {h[1] for h in want} == {0, 3}
+
+
+def test_five_byte_literals_probe_every_second_byte():
+    """Sets whose literals all have >= 5 bytes: byte-aligned probing at even offsets only, two windows per literal; occurrences
+    at every alignment, across rows / tiles and at the end of the text."""
+    pats = ["ERROR", "panic", "(?i)Failed", "denied: [a-z]+", "needle_in_haystack", "x=\\d+;"]
+    flags = [14, 14, 14, 6, 14, 14]
+    ids = [0, 1, 2, 3, 4, 5]
+    db = hgsim_py.Db(pats, flags, ids)
+    assert db.ok(), db.error
+    assert db.selfcheck()["byte_windows"] == 2 and db.selfcheck()["violations"] == 0
+    assert [db.tier(i) for i in range(6)] == [0, 0, 0, 0, 0, 1]
+    rng = random.Random(91)
+    words = [b"ERROR", b"panic", b"FAILED", b"failed", b"denied: abc", b"needle_in_haystack", b"x=12;", b"ERRO", b"pani", b"faile", b"denied:", b"ERRORERROR"]
+    for trial in range(6):
+        out = bytearray()
+        while len(out) < 40000:
+            line = bytearray()
+            for _ in range(rng.randint(0, 6)):
+                line += rng.choice(words) if rng.random() < 0.5 else bytes(rng.choice(b"abcdefoOrRE =.;0123") for _ in range(rng.randint(1, 9)))
+                if rng.random() < 0.5:
+                    line += b" "
+            out += line + b"\n"
+        for at in (1019, 1020, 1021, 1022, 1023, 2045, 16379, 16380, 16381, 16382, 16383, 32765):
+            out[at:at + 5] = b"ERROR"
+            out[at + 3000:at + 3005] = b"panic"
+        data = bytes(out[:39000 + trial]) + rng.choice([b"panic", b"ERROR", b"ERROR\n", b"pani"])
+        want, _ = oracle_hits(data, pats, flags, ids)
+        got, _ = db.scan(data)
+        assert sorted(got) == want, trial
+        tuned = hgsim_py.Db(pats, flags, ids)
+        assert tuned.tune(data[:20000]) == 0 and tuned.selfcheck()["violations"] == 0
+        assert sorted(tuned.scan(data)[0]) == want, trial
 
 
 def test_many_three_byte_literals_use_three_byte_windows():

@@ -767,3 +767,40 @@ def test_skewed_hits_one_long_line_all_matches(torch_cuda):
     got, stats = gpu_scan_buffer(torch_cuda, data, pats, flags, ids)
     assert stats.n_lines == nlines and got == want
     assert len(want) > 50000 and stats.n_raw_hits > 1000000
+
+
+@pytest.mark.gpu
+def test_five_byte_literals_probe_every_second_byte(torch_cuda):
+    """Every required literal of the set has >= 5 bytes: byte-aligned probing at even offsets only (two windows per literal,
+    eight probes per 16 bytes).  Occurrences at every alignment, across rows, tiles and the end of the text, NULs, small buffers."""
+    from hypergrep_amd import device
+
+    pats = ["ERROR", "panic", "(?i)Failed", "denied: [a-z]+", "needle_in_haystack", "x=\\d+;", "\\bGET\\b /api"]
+    flags = [14, 14, 14, 6, 14, 14, 14]
+    ids = [0, 1, 2, 3, 4, 5, 5]
+    info = device.Database(pats, flags, ids).info()
+    assert info["byte_windows"] == 2 and info["n_always_on"] == 1 and info["n_windows"] == 2 * info["n_factors"]
+    rng = random.Random(92)
+    words = [b"ERROR", b"panic", b"FAILED", b"failed", b"denied: abc", b"needle_in_haystack", b"x=12;", b"ERRO", b"pani", b"faile", b"denied:",
+             b"ERRORERROR", b"GET /api", b"GETS /api"]
+    for trial in range(3):
+        out = bytearray()
+        while len(out) < 300000:
+            line = bytearray()
+            for _ in range(rng.choice([0, 2, 6, 6, 40])):
+                line += rng.choice(words) if rng.random() < 0.4 else bytes(rng.choice(b"abcdefoOrRE =.;0123") for _ in range(rng.randint(1, 9)))
+                if rng.random() < 0.5:
+                    line += b" "
+            if rng.random() < 0.02:
+                line[len(line) // 2:len(line) // 2] = b"\0"
+            out += line + b"\n"
+        out[100000:100000] = b"z" * 30000 + b" ERROR panic " + b"y" * 20000
+        for at in (1019, 1020, 1021, 1022, 1023, 2045, 16379, 16380, 16381, 16382, 16383, 32765, 65533):
+            out[at:at + 5] = b"ERROR"
+            out[at + 3000:at + 3005] = b"panic"
+        data = bytes(out[:290000 + trial]) + rng.choice([b"panic", b"ERROR", b"ERROR\n", b"pani"])
+        for bs in (262140, 4096):
+            want, nlines = oracle_hits(data, pats, flags, ids, buffer_size=bs)
+            got, stats = gpu_scan_buffer(torch_cuda, data, pats, flags, ids, buffer_size=bs)
+            assert stats.n_lines == nlines and got == want, (trial, bs)
+        assert len(want) > 3000
