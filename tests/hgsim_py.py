@@ -25,8 +25,10 @@ def build() -> None:
     deps = [SRC] + [os.path.join(CSRC, f) for f in ("hg_compile.cpp", "hg_compile.h", "hg_core.h", "hg_db.h", "hg_post.h")]
     if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
         return
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", LIB, SRC,
-                           os.path.join(CSRC, "hg_compile.cpp")])
+    # built aside and renamed into place: parallel test workers (pytest -n) may all find the library stale at once
+    tmp = f"{LIB}.{os.getpid()}.tmp"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-o", tmp, SRC, os.path.join(CSRC, "hg_compile.cpp")])
+    os.replace(tmp, LIB)
 
 
 def lib() -> ctypes.CDLL:
