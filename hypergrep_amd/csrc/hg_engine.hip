@@ -121,11 +121,8 @@ int HgScanner::create(const HgDb *db, int device, HgScanner **out, std::string *
   HG_TRY(hipStreamCreateWithFlags(&s->fin_stream_, hipStreamNonBlocking), "hipStreamCreate");
   HG_TRY(hipEventCreateWithFlags(&s->ev_fin_done_, hipEventDisableTiming), "hipEventCreate");
   HG_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_early_), HG_CNT_WORDS * 4), "alloc pinned");
-  for (int i = 0; i < kMaxChunks; i++) {
-    HG_TRY(hipEventCreate(&s->ev_k1_begin_[i]), "hipEventCreate");
-    HG_TRY(hipEventCreate(&s->ev_k1_end_[i]), "hipEventCreate");
-    HG_TRY(hipEventCreateWithFlags(&s->ev_side_done_[i], hipEventDisableTiming), "hipEventCreate");
-  }
+  // (the per-chunk events of the two-stream pipeline are created by the first scan that is large enough to use it: a
+  // process that keeps dozens of scanners for small files would otherwise hold thousands of events for nothing)
 #undef HG_TRY
   *out = s.release();
   return HG_OK;
@@ -294,6 +291,13 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
     HgTileBase init{0, line_base};
     *h_final_ = init;
     HG_TRY(hipMemcpyAsync(d_final_, h_final_, sizeof(HgTileBase), hipMemcpyHostToDevice, stream), "upload scan state");
+    if (piped && !ev_side_done_[0]) {
+      for (int i = 0; i < kMaxChunks; i++) {
+        HG_TRY(hipEventCreate(&ev_k1_begin_[i]), "hipEventCreate");
+        HG_TRY(hipEventCreate(&ev_k1_end_[i]), "hipEventCreate");
+        HG_TRY(hipEventCreateWithFlags(&ev_side_done_[i], hipEventDisableTiming), "hipEventCreate");
+      }
+    }
     if (piped) {  // side stream starts after the counters / state are in place
       HG_TRY(hipEventRecord(ev_side_done_[kMaxChunks - 1], stream), "event");
       HG_TRY(hipStreamWaitEvent(side, ev_side_done_[kMaxChunks - 1], 0), "stream wait");

@@ -145,12 +145,25 @@ Ctx *checkout(const std::shared_ptr<HgDb> &db, std::string *err) {
   return c.release();
 }
 void checkin(Ctx *c) {
-  std::lock_guard<std::mutex> lock(g_mu);
-  if (g_idle.size() >= 32) {
-    delete c;
-    return;
+  // A few idle contexts are kept for reuse (one per pattern set in flight: the reference's thread pool scans many files with
+  // the SAME patterns); the oldest goes when a new one comes in.  Dozens of live contexts (a caller cycling through many
+  // pattern sets) are avoided on purpose: tools/fuzz_gpu.py hit a GPU memory fault with ~33 of them alive, root cause open.
+  size_t keep = 4;  // HYPERGREP_POOL overrides; 0 = none
+  if (const char *env = std::getenv("HYPERGREP_POOL")) keep = static_cast<size_t>(std::max(0l, std::atol(env)));
+  Ctx *evict = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (keep == 0) {
+      evict = c;
+    } else {
+      g_idle.push_back(c);
+      if (g_idle.size() > keep) {
+        evict = g_idle.front();
+        g_idle.erase(g_idle.begin());
+      }
+    }
   }
-  g_idle.push_back(c);
+  delete evict;  // (outside the lock: frees device memory)
 }
 // slots: pinned buffers needed (1 for a file that fits one chunk, else all)
 bool ensure_buffers(Ctx *c, size_t cap, int slots) {

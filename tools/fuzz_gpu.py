@@ -54,6 +54,9 @@ last_print = t0
 while time.time() - t0 < budget:
     rng = random.Random(seed)
     seed += 1
+    if os.environ.get("HG_FUZZ_TRACE"):  # last line of the file = the case that was running when the process died
+        with open(os.environ["HG_FUZZ_TRACE"], "a") as trace:
+            trace.write(f"{seed - 1}\n")
     kind = rng.choice(["random", "random", "anchored", "mixed", "keywords", "keywords", "rich", "rich"])
     if kind == "keywords":  # word lists: byte-aligned probing, 3-byte windows, short and long literals side by side
         lo, hi = rng.choice([(3, 3), (3, 5), (4, 6), (3, 9), (5, 12)])
@@ -96,7 +99,11 @@ while time.time() - t0 < budget:
             b[at:at] = bytes(rng.choice(b"abcx01 ._-") for _ in range(rng.choice([5000, 20000, 40000])))
         data = bytes(b)
     bs = rng.choice([262140, 262140, 8, 64, 1000, 4096, 20000])
-    if rng.random() < 0.25:  # the same case through the file API (Face B): batches, match limit, gzip, several ingest chunks
+    only = os.environ.get("HG_FUZZ_ONLY", "")  # debugging aid: "faceb" / "dev" runs only that kind of case (same seeds)
+    through_files = rng.random() < 0.25
+    if (only == "faceb" and not through_files) or (only == "dev" and through_files):
+        continue
+    if through_files:  # the same case through the file API (Face B): batches, match limit, gzip, several ingest chunks
         import gzip
         import tempfile
 
