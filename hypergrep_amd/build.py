@@ -15,6 +15,10 @@ REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIB_DIR, "libhyperscanner.so")
+# Face A artefact: the same objects linked once more with SONAME libhs.so.5, which is what the reference shim's DT_NEEDED
+# asks for: hypergrep.configure_libraries(libhs=<this file>) puts the GPU engine under the reference's
+# own prebuilt shim.
+LIBHS_NAME = "libhs.so.5"
 OBJ = os.path.join(REPO, "build", "obj")
 # Experiment builds (tools/variant_bench.py): extra -D flags and another output path, e.g.
 #   HG_BUILD_DEFINES="-DHG_STREAM_WAVES=6" HG_BUILD_OUT=build/variants/w6.so python hypergrep_amd/build.py
@@ -23,10 +27,11 @@ if os.environ.get("HG_BUILD_OUT"):
     LIB = os.path.abspath(os.environ["HG_BUILD_OUT"])
     LIB_DIR = os.path.dirname(LIB)
     OBJ = LIB + ".obj"
+    LIBHS_NAME = os.path.basename(LIB) + ".libhs.so.5"
 
 HIP_SOURCES = ["hg_kernels.hip", "hg_engine.hip", "hg_capi.hip", "hg_shim.hip", "hg_hsface.hip"]
 CXX_SOURCES = ["hg_compile.cpp"]
-HEADERS = ["hg_db.h", "hg_core.h", "hg_post.h", "hg_engine.h", "hg_compile.h", "hg_synth.h", "hg_confirm_dev.h"]
+HEADERS = ["hg_mem.h", "hg_db.h", "hg_core.h", "hg_post.h", "hg_engine.h", "hg_compile.h", "hg_synth.h", "hg_confirm_dev.h"]
 
 
 def _hipcc() -> str:
@@ -102,6 +107,13 @@ def build(verbose: bool = False, force: bool = False) -> str:
     if force or _stale(LIB, objs + [os.path.join(CSRC, "exports.map")]):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs + ["-lz", "-ldl", "-Wl,-Bsymbolic", "-Wl,-soname,libhyperscanner.so",
                                                                                 "-Wl,--version-script=" + os.path.join(CSRC, "exports.map")]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    libhs = os.path.join(LIB_DIR, LIBHS_NAME)
+    if force or _stale(libhs, objs + [os.path.join(CSRC, "exports.map")]):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", libhs] + objs + ["-lz", "-ldl", "-Wl,-Bsymbolic", "-Wl,-soname,libhs.so.5",
+                                                                                  "-Wl,--version-script=" + os.path.join(CSRC, "exports.map")]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

@@ -8,6 +8,7 @@
 #include <memory>
 
 #include "hg_engine.h"
+#include "hg_mem.h"
 
 #include <rocprim/rocprim.hpp>
 
@@ -41,9 +42,9 @@ constexpr int TS_BLOCK_TILES = 1024;  // must match hg_kernels.hip (256 threads 
 constexpr int STREAM_WG_WAVES = HG_STREAM_WG_WAVES;
 
 template <typename T>
-hipError_t upload(void **dst, const std::vector<T> &src) {
+hipError_t upload(void **dst, const std::vector<T> &src, const char *name) {
   size_t bytes = std::max<size_t>(src.size() * sizeof(T), 16);
-  hipError_t e = hipMalloc(dst, bytes);
+  hipError_t e = hgmem::dev_alloc(dst, bytes, name);
   if (e != hipSuccess) return e;
   if (!src.empty()) e = hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
   return e;
@@ -85,17 +86,17 @@ int HgScanner::create(const HgDb *db, int device, HgScanner **out, std::string *
   hipDeviceProp_t prop;
   HG_TRY(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties");
   s->num_cus_ = prop.multiProcessorCount;
-  HG_TRY(upload(&s->d_patterns_, db->patterns), "upload patterns");
-  HG_TRY(upload(&s->d_pool_, db->pool), "upload tables");
-  HG_TRY(upload(&s->d_factors_, db->factors), "upload factors");
-  HG_TRY(upload(&s->d_windows_, db->windows), "upload windows");
-  HG_TRY(upload(&s->d_bucket_, db->bucket_off), "upload buckets");
-  HG_TRY(upload(&s->d_disc_, db->disc), "upload discriminators");
-  HG_TRY(upload(&s->d_bucket2_, db->bucket_off2), "upload buckets");
-  HG_TRY(upload(&s->d_windows2_, db->windows2), "upload windows");
-  HG_TRY(upload(&s->d_filter_, db->filter), "upload filter");
-  HG_TRY(upload(&s->d_ext_, db->ext), "upload filter conditions");
-  HG_TRY(upload(&s->d_slow_, db->slow), "upload always-on list");
+  HG_TRY(upload(&s->d_patterns_, db->patterns, "d_patterns_"), "upload patterns");
+  HG_TRY(upload(&s->d_pool_, db->pool, "d_pool_"), "upload tables");
+  HG_TRY(upload(&s->d_factors_, db->factors, "d_factors_"), "upload factors");
+  HG_TRY(upload(&s->d_windows_, db->windows, "d_windows_"), "upload windows");
+  HG_TRY(upload(&s->d_bucket_, db->bucket_off, "d_bucket_"), "upload buckets");
+  HG_TRY(upload(&s->d_disc_, db->disc, "d_disc_"), "upload discriminators");
+  HG_TRY(upload(&s->d_bucket2_, db->bucket_off2, "d_bucket2_"), "upload buckets");
+  HG_TRY(upload(&s->d_windows2_, db->windows2, "d_windows2_"), "upload windows");
+  HG_TRY(upload(&s->d_filter_, db->filter, "d_filter_"), "upload filter");
+  HG_TRY(upload(&s->d_ext_, db->ext, "d_ext_"), "upload filter conditions");
+  HG_TRY(upload(&s->d_slow_, db->slow, "d_slow_"), "upload always-on list");
   s->view_.patterns = static_cast<const HgPattern *>(s->d_patterns_);
   s->view_.pool = static_cast<const uint32_t *>(s->d_pool_);
   s->view_.factors = static_cast<const HgFactor *>(s->d_factors_);
@@ -110,17 +111,17 @@ int HgScanner::create(const HgDb *db, int device, HgScanner **out, std::string *
   s->view_.nslow_fast = db->nslow_fast;
   s->view_.fold_mask = db->fold_mask;
   s->view_.window_mask = db->window_mask;
-  HG_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_counters_), HG_CNT_WORDS * 4), "alloc counters");
-  HG_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_selected_), 16), "alloc counters");
-  HG_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_final_), sizeof(HgTileBase)), "alloc state");
-  HG_TRY(hipMalloc(reinterpret_cast<void **>(&s->d_pflags_), db->patterns.size() * 4 + 16), "alloc pattern flags");
-  HG_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_counters_), (HG_CNT_WORDS + 4 + HG_DEFER_SHARDS) * 4), "alloc pinned");
-  HG_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_final_), sizeof(HgTileBase)), "alloc pinned");
+  HG_TRY(hgmem::dev_alloc(&s->d_counters_, HG_CNT_WORDS * 4, "d_counters_"), "alloc counters");
+  HG_TRY(hgmem::dev_alloc(&s->d_selected_, 16, "d_selected_"), "alloc counters");
+  HG_TRY(hgmem::dev_alloc(&s->d_final_, sizeof(HgTileBase), "d_final_"), "alloc state");
+  HG_TRY(hgmem::dev_alloc(&s->d_pflags_, db->patterns.size() * 4 + 16, "d_pflags_"), "alloc pattern flags");
+  HG_TRY(hgmem::host_alloc(&s->h_counters_, (HG_CNT_WORDS + 4 + HG_DEFER_SHARDS) * 4, "h_counters_"), "alloc pinned");
+  HG_TRY(hgmem::host_alloc(&s->h_final_, sizeof(HgTileBase), "h_final_"), "alloc pinned");
   for (auto &ev : s->ev_) HG_TRY(hipEventCreate(&ev), "hipEventCreate");
   HG_TRY(hipStreamCreateWithFlags(&s->side_stream_, hipStreamNonBlocking), "hipStreamCreate");
   HG_TRY(hipStreamCreateWithFlags(&s->fin_stream_, hipStreamNonBlocking), "hipStreamCreate");
   HG_TRY(hipEventCreateWithFlags(&s->ev_fin_done_, hipEventDisableTiming), "hipEventCreate");
-  HG_TRY(hipHostMalloc(reinterpret_cast<void **>(&s->h_early_), HG_CNT_WORDS * 4), "alloc pinned");
+  HG_TRY(hgmem::host_alloc(&s->h_early_, HG_CNT_WORDS * 4, "h_early_"), "alloc pinned");
   // (the per-chunk events of the two-stream pipeline are created by the first scan that is large enough to use it: a
   // process that keeps dozens of scanners for small files would otherwise hold thousands of events for nothing)
 #undef HG_TRY
@@ -133,10 +134,9 @@ HgScanner::~HgScanner() {
   void *ptrs[] = {d_patterns_, d_pool_, d_factors_, d_windows_, d_bucket_, d_filter_, d_ext_, d_slow_, d_sums_, d_bases_, d_block_base_,
                   d_final_, d_agg_, d_cands_, d_hits_raw_, d_hits_out_, d_aux_raw_, d_aux_out_,
                   d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, d_keep_, d_counters_, d_selected_, d_temp_, d_seg_count_, d_pflags_, d_deferred_, d_defer_count_, d_seg_count2_, d_cands2_, d_disc_, d_bucket2_, d_windows2_};
-  for (void *p : ptrs)
-    if (p) (void)hipFree(p);
-  if (h_counters_) (void)hipHostFree(h_counters_);
-  if (h_final_) (void)hipHostFree(h_final_);
+  for (void *p : ptrs) hgmem::dev_free(p, "scanner");
+  hgmem::host_free(h_counters_, "h_counters_");
+  hgmem::host_free(h_final_, "h_final_");
   for (auto &ev : ev_)
     if (ev) (void)hipEventDestroy(ev);
   for (int i = 0; i < kMaxChunks; i++) {
@@ -147,36 +147,36 @@ HgScanner::~HgScanner() {
   if (side_stream_) (void)hipStreamDestroy(side_stream_);
   if (fin_stream_) (void)hipStreamDestroy(fin_stream_);
   if (ev_fin_done_) (void)hipEventDestroy(ev_fin_done_);
-  if (h_early_) (void)hipHostFree(h_early_);
+  hgmem::host_free(h_early_, "h_early_");
 }
 
 int HgScanner::alloc_cands(uint64_t n) {
   n = std::min<uint64_t>(n, 0x7FFFFFF0u);
-  if (d_cands_) (void)hipFree(d_cands_);
+  hgmem::dev_free(d_cands_, "d_cands_");
   d_cands_ = nullptr;
-  if (fail(hipMalloc(reinterpret_cast<void **>(&d_cands_), n * sizeof(HgCand)), "workspace alloc (candidates)")) return HG_ERR_HIP;
-  if (d_cands2_) (void)hipFree(d_cands2_);
+  if (fail(hgmem::dev_alloc(&d_cands_, n * sizeof(HgCand), "d_cands_"), "workspace alloc (candidates)")) return HG_ERR_HIP;
+  hgmem::dev_free(d_cands2_, "d_cands2_");
   d_cands2_ = nullptr;
-  if (fail(hipMalloc(reinterpret_cast<void **>(&d_cands2_), n * sizeof(HgCand)), "workspace alloc (candidates)")) return HG_ERR_HIP;
-  if (d_deferred_) (void)hipFree(d_deferred_);
+  if (fail(hgmem::dev_alloc(&d_cands2_, n * sizeof(HgCand), "d_cands2_"), "workspace alloc (candidates)")) return HG_ERR_HIP;
+  hgmem::dev_free(d_deferred_, "d_deferred_");
   d_deferred_ = nullptr;
   // verified occurrences: one set of sharded lists per confirm mode the database uses
   uint32_t modes = 0;
   for (uint32_t m = 0; m < HG_CONFIRM_MODES; m++) modes += db_->n_confirm_mode[m] ? 1 : 0;
-  if (fail(hipMalloc(reinterpret_cast<void **>(&d_deferred_), std::max<uint64_t>(modes, 1) * n * sizeof(HgDeferred)), "workspace alloc (deferred)")) return HG_ERR_HIP;
+  if (fail(hgmem::dev_alloc(&d_deferred_, std::max<uint64_t>(modes, 1) * n * sizeof(HgDeferred), "d_deferred_"), "workspace alloc (deferred)")) return HG_ERR_HIP;
   cand_cap_ = static_cast<uint32_t>(n);
   return HG_OK;
 }
 
 int HgScanner::alloc_hits(uint64_t n64) {
   const uint32_t n = static_cast<uint32_t>(std::min<uint64_t>(n64, 0x7FFFFFF0u));
-  auto re = [&](auto *&ptr, size_t count) -> bool {
-    if (ptr) (void)hipFree(ptr);
+  auto re = [&](auto *&ptr, size_t count, const char *name) -> bool {
+    hgmem::dev_free(ptr, name);
     ptr = nullptr;
-    return fail(hipMalloc(reinterpret_cast<void **>(&ptr), std::max<size_t>(count * sizeof(*ptr), 16)), "workspace alloc (hits)");
+    return fail(hgmem::dev_alloc(&ptr, std::max<size_t>(count * sizeof(*ptr), 16), name), "workspace alloc (hits)");
   };
-  if (re(d_hits_raw_, n) || re(d_hits_out_, n) || re(d_aux_raw_, n) || re(d_aux_out_, n) ||
-      re(d_key_a_, n) || re(d_key_b_, n) || re(d_perm_a_, n) || re(d_perm_b_, n) || re(d_keep_, n))
+  if (re(d_hits_raw_, n, "d_hits_raw_") || re(d_hits_out_, n, "d_hits_out_") || re(d_aux_raw_, n, "d_aux_raw_") || re(d_aux_out_, n, "d_aux_out_") ||
+      re(d_key_a_, n, "d_key_a_") || re(d_key_b_, n, "d_key_b_") || re(d_perm_a_, n, "d_perm_a_") || re(d_perm_b_, n, "d_perm_b_") || re(d_keep_, n, "d_keep_"))
     return HG_ERR_HIP;
   hit_cap_ = n;
   size_t t1 = 0, t2 = 0;
@@ -186,9 +186,9 @@ int HgScanner::alloc_hits(uint64_t n64) {
   (void)rocprim::merge(nullptr, t3, d_key_a_, d_key_a_, d_key_b_, d_perm_a_, d_perm_a_, d_perm_b_, n, n, rocprim::less<uint64_t>(), hipStream_t(nullptr));
   size_t need = std::max(std::max(t1, t2), t3) + 256;
   if (need > temp_bytes_) {
-    if (d_temp_) (void)hipFree(d_temp_);
+    hgmem::dev_free(d_temp_, "d_temp_");
     d_temp_ = nullptr;
-    if (fail(hipMalloc(&d_temp_, need), "workspace alloc (sort)")) return HG_ERR_HIP;
+    if (fail(hgmem::dev_alloc(&d_temp_, need, "d_temp_"), "workspace alloc (sort)")) return HG_ERR_HIP;
     temp_bytes_ = need;
   }
   return HG_OK;
@@ -196,19 +196,19 @@ int HgScanner::alloc_hits(uint64_t n64) {
 
 int HgScanner::ensure(uint64_t nbytes) {
   uint64_t ntiles = std::max<uint64_t>((nbytes + HG_TILE_BYTES - 1) / HG_TILE_BYTES, 1);
-  auto re = [&](auto *&ptr, size_t count) -> bool {
-    if (ptr) (void)hipFree(ptr);
+  auto re = [&](auto *&ptr, size_t count, const char *name) -> bool {
+    hgmem::dev_free(ptr, name);
     ptr = nullptr;
-    return fail(hipMalloc(reinterpret_cast<void **>(&ptr), std::max<size_t>(count * sizeof(*ptr), 16)), "workspace alloc");
+    return fail(hgmem::dev_alloc(&ptr, std::max<size_t>(count * sizeof(*ptr), 16), name), "workspace alloc");
   };
   if (ntiles > cap_tiles_) {
     uint64_t nblocks = (ntiles + TS_BLOCK_TILES - 1) / TS_BLOCK_TILES;
-    if (re(d_sums_, ntiles) || re(d_bases_, ntiles + 1) || re(d_agg_, nblocks) || re(d_block_base_, nblocks)) return HG_ERR_HIP;
+    if (re(d_sums_, ntiles, "d_sums_") || re(d_bases_, ntiles + 1, "d_bases_") || re(d_agg_, nblocks, "d_agg_") || re(d_block_base_, nblocks, "d_block_base_")) return HG_ERR_HIP;
     cap_tiles_ = ntiles;
   }
   if (!d_seg_count_) {
     max_segs_ = static_cast<uint32_t>(num_cus_) * 16;
-    if (re(d_seg_count_, max_segs_) || re(d_seg_count2_, max_segs_) || re(d_defer_count_, HG_CONFIRM_MODES * HG_DEFER_SHARDS)) return HG_ERR_HIP;
+    if (re(d_seg_count_, max_segs_, "d_seg_count_") || re(d_seg_count2_, max_segs_, "d_seg_count2_") || re(d_defer_count_, HG_CONFIRM_MODES * HG_DEFER_SHARDS, "d_defer_count_")) return HG_ERR_HIP;
   }
   // one candidate / hit per KiB of text to start with; grows (and the pass repeats) on overflow
   uint64_t want = std::max<uint64_t>(nbytes / 1024, 1u << 16);
@@ -585,6 +585,7 @@ int HgScanner::scan_impl(const void *d_text, uint64_t nbytes, int buffer_size, u
   const uint64_t bs1 = static_cast<uint64_t>(buffer_size) - 1;
   if (fail(hipSetDevice(device_), "hipSetDevice")) return HG_ERR_HIP;
   std::memset(out, 0, sizeof(*out));
+  if (hgmem::log_file()) hgmem::note("scan  %p text %p .. %p  %llu  bs %d block %d\n", static_cast<void *>(this), d_text, static_cast<const void *>(static_cast<const char *>(d_text) + nbytes), static_cast<unsigned long long>(nbytes), buffer_size, block_mode ? 1 : 0);
   int rc = ensure(nbytes);
   if (rc) return rc;
   uint32_t reruns = 0;

@@ -16,6 +16,7 @@
 #include "../../include/hypergrep_amd.h"
 #include "hg_compile.h"
 #include "hg_engine.h"
+#include "hg_mem.h"
 
 struct hs_database {
   std::shared_ptr<HgDb> db;
@@ -88,7 +89,7 @@ int hs_free_scratch(hs_scratch_t *scratch) {
   if (!scratch) return HS_SUCCESS;
   if (scratch->sc) (void)hipSetDevice(scratch->sc->device());
   delete scratch->sc;
-  if (scratch->d_text) (void)hipFree(scratch->d_text);
+  hgmem::dev_free(scratch->d_text, "hs d_text");
   if (scratch->stream) (void)hipStreamDestroy(scratch->stream);
   delete scratch;
   return HS_SUCCESS;
@@ -101,10 +102,10 @@ int hs_scan(const hs_database_t *db, const char *data, unsigned int length, unsi
   if (length == 0) return HS_SUCCESS;  // no expression can match the empty buffer (such expressions are rejected at compile time)
   if (hipSetDevice(scratch->sc->device()) != hipSuccess) return HS_INVALID;
   if (scratch->d_cap < length) {
-    if (scratch->d_text) (void)hipFree(scratch->d_text);
+    hgmem::dev_free(scratch->d_text, "hs d_text");
     scratch->d_text = nullptr;
     size_t cap = std::max<size_t>(length, 4096) * 2;
-    if (hipMalloc(reinterpret_cast<void **>(&scratch->d_text), cap + 16) != hipSuccess) return HS_NOMEM;
+    if (hgmem::dev_alloc(&scratch->d_text, cap + 16, "hs d_text") != hipSuccess) return HS_NOMEM;
     scratch->d_cap = cap;
   }
   if (hipMemcpyAsync(scratch->d_text, data, length, hipMemcpyHostToDevice, scratch->stream) != hipSuccess) return HS_INVALID;

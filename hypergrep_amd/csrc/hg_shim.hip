@@ -37,6 +37,7 @@
 #include "../../include/hypergrep_amd.h"
 #include "hg_compile.h"
 #include "hg_engine.h"
+#include "hg_mem.h"
 
 namespace {
 
@@ -100,10 +101,8 @@ struct Ctx {
   ~Ctx() {
     if (sc) (void)hipSetDevice(device);
     delete sc;
-    for (uint8_t *p : h_slot)
-      if (p) (void)hipHostFree(p);
-    for (uint8_t *p : d_text)
-      if (p) (void)hipFree(p);
+    for (uint8_t *p : h_slot) hgmem::host_free(p, "h_slot");
+    for (uint8_t *p : d_text) hgmem::dev_free(p, "d_text");
     for (hipEvent_t e : ev_h2d)
       if (e) (void)hipEventDestroy(e);
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
@@ -169,22 +168,22 @@ void checkin(Ctx *c) {
 bool ensure_buffers(Ctx *c, size_t cap, int slots) {
   if (c->h_cap < cap) {
     for (uint8_t *&p : c->h_slot) {
-      if (p) (void)hipHostFree(p);
+      hgmem::host_free(p, "h_slot");
       p = nullptr;
     }
     c->h_cap = cap;
   }
   for (int i = 0; i < slots; i++)
-    if (!c->h_slot[i] && hipHostMalloc(reinterpret_cast<void **>(&c->h_slot[i]), c->h_cap) != hipSuccess) return false;
+    if (!c->h_slot[i] && hgmem::host_alloc(&c->h_slot[i], c->h_cap, "h_slot") != hipSuccess) return false;
   if (c->d_cap < cap) {
     for (uint8_t *&p : c->d_text) {
-      if (p) (void)hipFree(p);
+      hgmem::dev_free(p, "d_text");
       p = nullptr;
     }
     c->d_cap = cap;
   }
   for (int i = 0; i < (slots > 1 ? Ctx::kDevBufs : 1); i++)
-    if (!c->d_text[i] && hipMalloc(reinterpret_cast<void **>(&c->d_text[i]), c->d_cap + 16) != hipSuccess) return false;
+    if (!c->d_text[i] && hgmem::dev_alloc(&c->d_text[i], c->d_cap + 16, "d_text") != hipSuccess) return false;
   return true;
 }
 

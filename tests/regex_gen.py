@@ -130,3 +130,71 @@ def anchored_text(rng, samplers, nlines):
         sep = rng.choice([" ", " ", "", ","])
         lines.append(sep.join(toks))
     return ("\n".join(lines) + "\n").encode()
+
+
+def py_flags(flags: int) -> int:
+    import re
+
+    f = 0
+    if flags & 1:
+        f |= re.I
+    if flags & 2:
+        f |= re.S
+    if flags & 4:
+        f |= re.M
+    return f
+
+
+# ---- independent pin of match END offsets (`to`): they decide SINGLEMATCH selection and the delivery order inside a line
+# (hyperscanner.c:83-102 delivers in hs_scan's report order), and no reference fixture covers them
+# (test_hypergrep.py:668-687 pins only one report per line).  Python `re` is the independent engine: end offset e is a
+# match end iff some start s < e has a match of exactly [s, e) WITH the line's real context on both sides — a lookahead
+# that pins the distance to the end of the line keeps `$`, `\b` and `\Z` honest at e (re.fullmatch(pos, endpos) would
+# pretend the line ends at e), and `pos` keeps `^` / `\b` honest at s.
+import re  # noqa: E402
+
+_END_RE_CACHE: dict = {}
+
+
+def ends_by_brute_force(pat: str, flags: int, line: bytes) -> list[int]:
+    n = len(line)
+    ends = []
+    for e in range(1, n + 1):
+        key = (pat, flags, n - e)
+        cre = _END_RE_CACHE.get(key)
+        if cre is None:
+            cre = _END_RE_CACHE[key] = re.compile(b"(?:" + pat.encode() + b")(?=(?s:.{%d})\\Z)" % (n - e), py_flags(flags))
+        if any(cre.match(line, s) for s in range(e)):
+            ends.append(e)
+    return ends
+
+
+def split_pieces(data: bytes) -> list[bytes]:
+    pieces = data.split(b"\n")
+    return [p + b"\n" for p in pieces[:-1]] + ([pieces[-1]] if pieces[-1] else [])
+
+
+def end_offset_cases(seed: int, per_seed: int = 16, accepts=None):
+    """(pattern, flags, text, [(line, to)]) cases; accepts(pattern, flags) filters out what the engine under test rejects."""
+    rng = random.Random(7000 + seed)
+    made = 0
+    for _ in range(400):
+        if made == per_seed:
+            break
+        pat = random_pattern(rng)
+        flags = rng.choice([6, 6, 7, 2, 4])  # all-matches mode (no SINGLEMATCH); caseless / non-multiline / no DOTALL variants
+        try:
+            re.compile(pat.encode(), py_flags(flags))
+        except re.error:
+            continue
+        if accepts is not None and not accepts(pat, flags):
+            continue
+        data = random_text(rng, 12, maxlen=14, final_newline=rng.random() < 0.8)
+        _END_RE_CACHE.clear()
+        want = []  # (line, to)
+        for i, line in enumerate(split_pieces(data)):
+            want += [(i, e) for e in ends_by_brute_force(pat, flags, line)]
+        made += 1
+        yield pat, flags, data, want
+
+

@@ -130,3 +130,60 @@ def test_streaming_kernels_stay_in_registers():
         assert names, prefix
         for name in names:
             assert table[name]["ScratchSize [bytes/lane]"] == 0 and table[name]["VGPRs Spill"] == 0, (name, table[name])
+
+
+def test_face_a_artefact_has_the_soname_the_reference_shim_needs():
+    """hypergrep/utils.py:63,75 loads the configured libhs first; the shim's DT_NEEDED `libhs.so.5` is then satisfied only
+    by an object whose SONAME is exactly that.  The build links hypergrep_amd/lib/libhs.so.5 for it."""
+    libhs = os.path.join(REPO, "hypergrep_amd", "lib", "libhs.so.5")
+    assert os.path.exists(libhs), "hypergrep_amd/build.py did not produce the Face A artefact"
+    dyn = subprocess.check_output(["readelf", "-d", libhs], text=True)
+    assert re.search(r"SONAME.*\[libhs\.so\.5\]", dyn)
+    lib = ctypes.CDLL(libhs, mode=os.RTLD_NOW)
+    for name in ("hs_compile_multi", "hs_free_compile_error", "hs_alloc_scratch", "hs_scan", "hs_free_scratch", "hs_free_database"):
+        assert hasattr(lib, name), name
+    # unversioned symbols, like the ones the shipped shim imports
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", libhs], text=True)
+    assert re.search(r" T hs_scan$", syms, flags=re.M)
+    # compile-only entry points work without a GPU through this object too; the free functions accept NULL
+    # (hyperscanner.c:140 after a success, :323-324 on the error paths)
+    db = ctypes.c_void_p()
+    pa = (ctypes.c_char_p * 1)(b"foo[0-9]+bar")
+    fa = (ctypes.c_uint * 1)(14)
+    ia = (ctypes.c_uint * 1)(0)
+    assert lib.hs_compile_multi(pa, fa, ia, 1, 1, None, ctypes.byref(db), None) == 0 and db.value
+    assert lib.hs_free_compile_error(None) == 0 and lib.hs_free_scratch(None) == 0
+    assert lib.hs_free_database(db) == 0 and lib.hs_free_database(None) == 0
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/hypergrep/lib/libhyperscanner.so"), reason="build container only: needs the reference tree")
+def test_reference_loader_accepts_the_face_a_artefact():
+    """The north-star boundary, exercised with the reference's own files: its unmodified Python
+    (hypergrep/utils.py:125-144 configure_libraries, :55-83 loaders) loads hypergrep_amd/lib/libhs.so.5 as `libhs`, then its
+    unmodified prebuilt shim, whose DT_NEEDED libhs.so.5 binds to that object; check_compatibility() (utils.py:97-121 ->
+    hyperscanner.c:154-167 -> hs_compile_multi) then runs this repository's compiler.  No GPU is needed for the compile path;
+    a scan through the same stack stops at hs_alloc_scratch without one (rc 3), never on a CPU fallback.  Runs in a child
+    process: the reference caches its library handles per process."""
+    import sys
+
+    libhs = os.path.join(REPO, "hypergrep_amd", "lib", "libhs.so.5")
+    code = (
+        "import sys, json; sys.path.insert(0, '/root/reference'); import hypergrep; "
+        f"hypergrep.configure_libraries(libhs={libhs!r}); "
+        "ok = hypergrep.check_compatibility(['foobar', 'status=5[0-9]{2}']); bad = hypergrep.check_compatibility(['(?<!a)b']); "
+        "maps = open('/proc/self/maps').read(); "
+        "rows, rc = hypergrep.grep('/root/reference/hypergrep/test/samplefile.txt', ['bar'], no_messages=True); "
+        "print(json.dumps({'ok': ok, 'bad': bad, 'ours': 'hypergrep_amd/lib/libhs.so.5' in maps, "
+        "'shim': '/root/reference/hypergrep/lib/libhyperscanner.so' in maps, 'rc': rc, 'rows': len(rows)}))"
+    )
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    import json
+
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["ok"] == 0 and res["bad"] == 4
+    assert res["ours"] and res["shim"], "the reference's shim did not bind to this repository's libhs.so.5"
+    import torch
+
+    if not torch.cuda.is_available():
+        assert res["rc"] == 3 and res["rows"] == 0  # HYPERSCANNER_SCRATCH: no GPU, and no CPU path

@@ -389,3 +389,20 @@ def test_random_literal_anchored_patterns_match_oracle(seed):
     got, _, db = sim_hits(data, pats, flags, ids)
     assert got == want, (pats, flags, ids)
     assert len(want) > 50 and db.info()["nslow"] == 0
+
+
+# ---- match END offsets of the product's automata against the Python-`re` brute force (regex_gen.ends_by_brute_force):
+# independent of the oracle, which the same brute force pins in tests/test_oracle.py
+@pytest.mark.parametrize("seed", range(20))
+def test_end_offsets_against_python_re(seed):
+    nonempty = 0
+    for pat, flags, data, want in regex_gen.end_offset_cases(seed, accepts=lambda p, f: hgsim_py.Db([p], [f]).ok()):
+        got, _, _ = sim_hits(data, [pat], [flags])
+        assert [(h[0], h[2]) for h in got] == want, (pat, flags, data)
+        got1, _, _ = sim_hits(data, [pat], [flags | 8])  # SINGLEMATCH: the smallest end offset of each line
+        first = {}
+        for line, to in want:
+            first.setdefault(line, to)
+        assert [(h[0], h[2]) for h in got1] == sorted(first.items()), (pat, flags, data)
+        nonempty += bool(want)
+    assert nonempty >= 2

@@ -804,3 +804,52 @@ def test_five_byte_literals_probe_every_second_byte(torch_cuda):
             got, stats = gpu_scan_buffer(torch_cuda, data, pats, flags, ids, buffer_size=bs)
             assert stats.n_lines == nlines and got == want, (trial, bs)
         assert len(want) > 3000
+
+
+# ------------------------------------------------------------------ Face A artefact under the shim's call sequence
+def _call_order_driver() -> str:
+    import subprocess
+
+    src = os.path.join(HERE, "native", "hs_call_order.c")
+    exe = os.path.join(HERE, "native", "hs_call_order")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-Wall", "-Wextra", "-o", exe, src, "-ldl"])
+    return exe
+
+
+def test_face_a_artefact_under_the_shim_call_order(torch_cuda, tmp_path):
+    """hypergrep_amd/lib/libhs.so.5 (SONAME libhs.so.5) driven by tests/native/hs_call_order.c, which replays the reference
+    shim's use of libhs (hyperscanner.c:136,140,301,217 per line piece,323,324 incl. the NULL frees), against the oracle's
+    libhs.so.5 driven by the same program: identical reports on the reference's data files and on a seeded text."""
+    import subprocess
+
+    exe = _call_order_driver()
+    product = os.path.join(os.path.dirname(HERE), "hypergrep_amd", "lib", "libhs.so.5")
+    oracle = os.path.join(oracle_py.ORACLE_DIR, "_build", "libhs.so.5")
+    assert os.path.exists(product) and os.path.exists(oracle)
+    rng = random.Random(77)
+    pairs = [regex_gen.anchored_pattern(rng) for _ in range(6)]
+    seeded = tmp_path / "seeded.txt"
+    seeded.write_bytes(regex_gen.anchored_text(rng, [s for _, s in pairs], 300) + b"\0\0lead " + b"x" * 300 + b"\nfoo\0bar\n")
+    cases = [
+        (os.path.join(FILES, "samplefile.txt"), 262140, [(14, 0, "bar"), (14, 1, "foo")]),
+        (os.path.join(FILES, "greptest1.txt"), 262140, [(14, 0, "[a-z]+ing\\b"), (6, 1, "the"), (15, 2, "THE")]),
+        (os.path.join(FILES, "greptest2.txt"), 64, [(14, 0, "\\d+"), (10, 3, "^.{3,8}$")]),
+        (str(seeded), 128, [(14, i, p) for i, (p, _) in enumerate(pairs)] + [(6, 9, "foo"), (14, 9, "x{5}")]),
+    ]
+    total = 0
+    for path, bs, pats in cases:
+        if not os.path.exists(path):
+            pytest.fail(f"fixture missing: {path}")
+        args = [str(x) for t in pats for x in t]
+        want = subprocess.run([exe, oracle, path, str(bs), "--"] + args, capture_output=True, text=True, timeout=120)
+        got = subprocess.run([exe, product, path, str(bs), "--"] + args, capture_output=True, text=True, timeout=300)
+        assert want.returncode == 0, want.stderr
+        assert got.returncode == 0, got.stderr
+        # inside one hs_scan call the oracle reports by ascending end offset, ties by id — so does the product
+        assert got.stdout == want.stdout, (path, pats)
+        total += len(want.stdout.splitlines())
+    assert total > 100
+    # a rejected expression: HYPERSCANNER_COMPILE (2) through the same sequence, error record freed
+    bad = subprocess.run([exe, product, cases[0][0], "64", "--", "14", "0", "(?<=a)b"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 2 and "compile failed" in bad.stderr

@@ -168,3 +168,31 @@ def test_dollar_and_boundaries():
     assert lines(b"foo_x\nfoo x\nxfoo\n", "\\bfoo\\b") == [1]
     assert lines(b"ab\n", "b\\n") == [0]  # the trailing newline is part of the scanned line
     assert lines(b"ab", "b\\n") == []
+
+
+# ---- independent pin of match END offsets (`to`): brute force over Python `re` (tests/regex_gen.py::ends_by_brute_force)
+@pytest.mark.parametrize("seed", range(20))
+def test_end_offsets_against_python_re(seed):
+    nonempty = 0
+    for pat, flags, data, want in regex_gen.end_offset_cases(seed, accepts=lambda p, f: oracle_py.check_patterns([p], flags=[f]) == 0):
+        rc, hits, _ = oracle_py.scan_buffer(data, [pat], flags=[flags])
+        assert rc == 0
+        assert [(h[0], h[2]) for h in hits] == want, (pat, flags, data)  # every distinct end offset, ascending inside a line
+        # SINGLEMATCH: one report per line, the smallest end offset
+        rc, hits1, _ = oracle_py.scan_buffer(data, [pat], flags=[flags | 8])
+        first = {}
+        for line, to in want:
+            first.setdefault(line, to)
+        assert [(h[0], h[2]) for h in hits1] == sorted(first.items()), (pat, flags, data)
+        nonempty += bool(want)
+    assert nonempty >= 2
+
+
+def test_end_offsets_known_answers():
+    # hand-checked: the brute force itself (so that a bug in it cannot hide behind agreement with the oracle)
+    assert regex_gen.ends_by_brute_force("abc", 6, b"xxabcabc\n") == [5, 8]
+    assert regex_gen.ends_by_brute_force("foo.*", 6, b"foobar\n") == [3, 4, 5, 6, 7]
+    assert regex_gen.ends_by_brute_force("foo$", 6, b"foo\n") == [3]          # `$` before the final newline only
+    assert regex_gen.ends_by_brute_force("o\\b", 6, b"foo bar\n") == [3]       # `\b` looks at the byte after the match
+    assert regex_gen.ends_by_brute_force("a+", 6, b"caab\n") == [2, 3]
+    assert regex_gen.ends_by_brute_force("^b", 6, b"ab\n") == []
