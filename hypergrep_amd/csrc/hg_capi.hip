@@ -2,6 +2,7 @@
 // synthetic-log generator kernel.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -13,7 +14,7 @@
 #include "hg_synth.h"
 
 struct hg_database {
-  HgDb *db;
+  std::shared_ptr<const HgDb> db;  // scanners share it; hg_db_tune swaps in a tuned copy, scanners made before keep theirs
 };
 struct hg_scanner {
   HgScanner *sc;
@@ -40,20 +41,21 @@ int hg_db_compile(const char *const *expressions, const unsigned int *flags, con
     put_err(err, errlen, std::to_string(bad) + ": " + msg);
     return rc == -2 ? HG_ERR_NOMEM : (rc == -1 ? HG_ERR_ARG : HG_ERR_COMPILE);
   }
-  *db = new hg_database{d};
+  *db = new hg_database{std::shared_ptr<const HgDb>(d, [](const HgDb *x) { hgc_free(const_cast<HgDb *>(x)); })};
   return HG_OK;
 }
 
 int hg_db_tune(hg_database_t *db, const void *sample, size_t nbytes) {
   if (!db || (!sample && nbytes)) return HG_ERR_ARG;
   std::string err;
-  return hgc_tune(db->db, static_cast<const uint8_t *>(sample), nbytes, &err) == 0 ? HG_OK : HG_ERR_COMPILE;
+  HgDb *tuned = nullptr;
+  if (hgc_tune(db->db.get(), static_cast<const uint8_t *>(sample), nbytes, &tuned, &err) != 0) return HG_ERR_COMPILE;  // (the database is unchanged)
+  db->db = std::shared_ptr<const HgDb>(tuned, [](const HgDb *x) { hgc_free(const_cast<HgDb *>(x)); });
+  return HG_OK;
 }
 
 void hg_db_release(hg_database_t *db) {
-  if (!db) return;
-  hgc_free(db->db);
-  delete db;
+  delete db;  // (scanners created from it keep the compiled tables alive)
 }
 
 int hg_db_info(const hg_database_t *db, hg_db_info_t *info) {
@@ -131,6 +133,68 @@ int hg_copy_hits_device(hg_scanner_t *scanner, void *d_dst, uint64_t max, void *
   if (hipMemcpyAsync(d_dst, scanner->last.d_hits, n * sizeof(hg_hit_t), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)) != hipSuccess)
     return HG_ERR_HIP;
   return HG_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------- guarded buffers (diagnostics / tests)
+// A device buffer whose END is followed by reserved but UNMAPPED address space: any read or write past the buffer's size
+// rounded up to 16 bytes is a GPU memory fault, wherever ordinary allocations would let it pass silently because the next
+// bytes happen to be mapped.  (Round 1's one GPU fault was such a read: it took ~50 live contexts before a text buffer
+// ended at the edge of a mapping.)  Built on the HIP virtual-memory API: reserve mapped + guard, map only the first part.
+struct hg_guarded {
+  void *base;
+  size_t mapped, reserved;
+  hipMemGenericAllocationHandle_t handle;
+};
+extern "C" {
+
+int hg_debug_alloc_guarded(uint64_t nbytes, int device, void **d_ptr, void **guard_handle) {
+  if (!d_ptr || !guard_handle) return HG_ERR_ARG;
+  *d_ptr = *guard_handle = nullptr;
+  if (hipSetDevice(device) != hipSuccess) return HG_ERR_HIP;
+  hipMemAllocationProp prop{};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = device;
+  size_t gran = 0;
+  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || !gran) return HG_ERR_HIP;
+  const size_t usable = (static_cast<size_t>(nbytes) + 15) & ~static_cast<size_t>(15);
+  auto g = std::make_unique<hg_guarded>();
+  g->mapped = std::max<size_t>((usable + gran - 1) / gran * gran, gran);
+  g->reserved = g->mapped + gran;
+  if (hipMemAddressReserve(&g->base, g->reserved, gran, nullptr, 0) != hipSuccess) return HG_ERR_HIP;
+  if (hipMemCreate(&g->handle, g->mapped, &prop, 0) != hipSuccess) {
+    (void)hipMemAddressFree(g->base, g->reserved);
+    return HG_ERR_HIP;
+  }
+  hipMemAccessDesc access{};
+  access.location = prop.location;
+  access.flags = hipMemAccessFlagsProtReadWrite;
+  if (hipMemMap(g->base, g->mapped, 0, g->handle, 0) != hipSuccess || hipMemSetAccess(g->base, g->mapped, &access, 1) != hipSuccess) {
+    (void)hipMemRelease(g->handle);
+    (void)hipMemAddressFree(g->base, g->reserved);
+    return HG_ERR_HIP;
+  }
+  *d_ptr = static_cast<char *>(g->base) + (g->mapped - usable);  // 16-byte aligned; [d_ptr, d_ptr + usable) ends at the guard
+  *guard_handle = g.release();
+  return HG_OK;
+}
+
+void hg_debug_free_guarded(void *guard_handle) {
+  hg_guarded *g = static_cast<hg_guarded *>(guard_handle);
+  if (!g) return;
+  (void)hipDeviceSynchronize();
+  (void)hipMemUnmap(g->base, g->mapped);
+  (void)hipMemRelease(g->handle);
+  (void)hipMemAddressFree(g->base, g->reserved);
+  delete g;
+}
+
+int hg_debug_upload(void *d_dst, const void *src, uint64_t nbytes) {
+  if (!nbytes) return HG_OK;
+  if (!d_dst || !src) return HG_ERR_ARG;
+  return hipMemcpy(d_dst, src, nbytes, hipMemcpyHostToDevice) == hipSuccess ? HG_OK : HG_ERR_HIP;
 }
 
 }  // extern "C"

@@ -1436,8 +1436,9 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
   return 0;
 }
 
-int hgc_tune(HgDb *db, const uint8_t *sample, size_t nbytes, std::string *err) {
-  if (!db || (!sample && nbytes)) return -1;
+int hgc_tune(const HgDb *db, const uint8_t *sample, size_t nbytes, HgDb **out, std::string *err) {
+  if (out) *out = nullptr;
+  if (!db || !out || (!sample && nbytes)) return -1;
   SampleStats st;
   const uint32_t fold = db->fold_mask;
   for (size_t p = 0; p + 4 <= nbytes; p += db->dense ? db->dense : 4) {
@@ -1450,9 +1451,18 @@ int hgc_tune(HgDb *db, const uint8_t *sample, size_t nbytes, std::string *err) {
     st.c6[static_cast<uint64_t>(w) | (static_cast<uint64_t>(nx & 0xFFFFu) << 32)]++;
   }
   st.dwords = nbytes / 4;
-  int rc = build_filter(*db, &st, err);
-  if (rc == 0) db->tuned = true;
-  return rc;
+  std::unique_ptr<HgDb> copy;
+  try {
+    copy = std::make_unique<HgDb>(*db);
+  } catch (const std::bad_alloc &) {
+    if (err) *err = "out of memory";
+    return -2;
+  }
+  int rc = build_filter(*copy, &st, err);  // a failure leaves the caller's database as it was
+  if (rc != 0) return rc;
+  copy->tuned = true;
+  *out = copy.release();
+  return 0;
 }
 
 void hgc_free(HgDb *db) { delete db; }

@@ -38,10 +38,12 @@ struct HgDb {
   bool tuned = false;
 };
 
+// Re-select the literal windows using byte statistics of a text sample (any part of the text to be scanned) and rebuild the
+// filter tables; never changes results, only how often the slow stages run.  The database itself is immutable once
+// compiled (scanners read it live): the tuned tables are built into a COPY, returned in *out only on success (0).
+int hgc_tune(const HgDb *db, const uint8_t *sample, size_t nbytes, HgDb **out, std::string *err);
+
 // Returns 0 on success.  On failure returns non-zero, sets *err and *bad_index (expression index or -1).
-// Re-select the literal windows using byte statistics of a text sample (any prefix of the text to be scanned) and
-// rebuild the filter tables; never changes results, only how often the slow stages run.  Returns 0 on success.
-int hgc_tune(HgDb *db, const uint8_t *sample, size_t nbytes, std::string *err);
 
 int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned *ids, unsigned n, HgDb **out,
                std::string *err, int *bad_index);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <memory>
 #include <string>
 
 #include "../../include/hypergrep_amd.h"
@@ -90,7 +91,9 @@ struct HgScanOutput {
 
 class HgScanner {
  public:
-  static int create(const HgDb *db, int device, HgScanner **out, std::string *err);
+  // The scanner shares ownership of the (immutable) database: launch parameters are read from it on every scan.
+  static int create(std::shared_ptr<const HgDb> db, int device, HgScanner **out, std::string *err);
+  const std::shared_ptr<const HgDb> &database() const { return db_; }
   ~HgScanner();
   // d_text: device pointer, 16-byte aligned, readable up to nbytes rounded up to 16.
   int scan(const void *d_text, uint64_t nbytes, int buffer_size, uint64_t line_base, hipStream_t stream, HgScanOutput *out);
@@ -115,7 +118,7 @@ class HgScanner {
   std::string err_;
   // database on device
   HgDbView view_{};
-  const HgDb *db_ = nullptr;
+  std::shared_ptr<const HgDb> db_;
   void *d_disc_ = nullptr, *d_bucket2_ = nullptr, *d_windows2_ = nullptr;
   void *d_patterns_ = nullptr, *d_pool_ = nullptr, *d_factors_ = nullptr, *d_windows_ = nullptr, *d_bucket_ = nullptr,
        *d_filter_ = nullptr, *d_ext_ = nullptr, *d_slow_ = nullptr;

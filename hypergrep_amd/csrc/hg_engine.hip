@@ -62,8 +62,12 @@ bool HgScanner::fail(hipError_t e, const char *what) {
   return true;
 }
 
-int HgScanner::create(const HgDb *db, int device, HgScanner **out, std::string *err) {
+int HgScanner::create(std::shared_ptr<const HgDb> db, int device, HgScanner **out, std::string *err) {
   *out = nullptr;
+  if (!db) {
+    if (err) *err = "no database";
+    return HG_ERR_ARG;
+  }
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count == 0) {

@@ -76,7 +76,7 @@ int hs_alloc_scratch(const hs_database_t *db, hs_scratch_t **scratch) {
   std::string err;
   int device = 0;
   if (const char *env = std::getenv("HYPERGREP_DEVICE")) device = std::atoi(env);
-  if (HgScanner::create(s->db.get(), device, &s->sc, &err) != HG_OK) {
+  if (HgScanner::create(s->db, device, &s->sc, &err) != HG_OK) {
     std::fprintf(stderr, "hypergrep_amd: hs_alloc_scratch: %s\n", err.c_str());
     return HS_NOMEM;
   }

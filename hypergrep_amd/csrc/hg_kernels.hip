@@ -209,7 +209,10 @@ __device__ __noinline__ void drain_batch(const StreamCtx cx, uint32_t first, uin
       rank = e_lo >> 10;
       cur = load_chunk_checked(cx.text16, cx.nbytes, g);
       nxt = load_dword_checked(cx.text16, cx.nbytes, (g + 1) << 4);
-      const uint32_t l1 = ProbeBytes<LOG2, DENSE ? DENSE : 1>::template probe16<false>(cx.filter, cx.fold, cx.wa, cx.wb, cur, nxt);
+      uint32_t l1 = ProbeBytes<LOG2, DENSE ? DENSE : 1>::template probe16<false>(cx.filter, cx.fold, cx.wa, cx.wb, cur, nxt);
+      // only windows that START inside the text (the bytes after a short literal at the very end read as zeros; a window
+      // past the end is nothing, and the neighbour reads below rely on pos < nbytes)
+      if ((g << 4) + 16 > cx.nbytes) l1 &= (g << 4) < cx.nbytes ? (1u << static_cast<uint32_t>(cx.nbytes - (g << 4))) - 1u : 0u;
       const uint32_t wbytes = (cx.wb >> 24) ? 4u : 3u, wmask = (cx.wb >> 24) ? 0xFFFFFFFFu : 0x00FFFFFFu;
       constexpr uint32_t BYTE_MASK = ((1u << LOG2) - 1u) << 2;
       const uint8_t *text = reinterpret_cast<const uint8_t *>(cx.text16);
@@ -223,7 +226,7 @@ __device__ __noinline__ void drain_batch(const StreamCtx cx, uint32_t first, uin
           prev = *reinterpret_cast<const hg_u32_unaligned *>(text + pos - 4);
           next = *reinterpret_cast<const hg_u32_unaligned *>(text + pos + wbytes);
         } else {
-          for (uint32_t b = 0; b < 4; b++) {
+          for (uint32_t b = 0; b < 4; b++) {  // (pos < nbytes, so pos + b - 4 is inside the text)
             if (pos + b >= 4) prev |= static_cast<uint32_t>(text[pos + b - 4]) << (8 * b);
             if (pos + wbytes + b < cx.nbytes) next |= static_cast<uint32_t>(text[pos + wbytes + b]) << (8 * b);
           }
@@ -281,7 +284,9 @@ __device__ __noinline__ void drain_batch(const StreamCtx cx, uint32_t first, uin
         have_left = have_right = true;
       }
     }
-    const uint32_t l1 = Probe<LOG2, WIDE>::template probe4<false>(cx.filter, cx.fold, cx.wa, cx.wb, cur);
+    uint32_t l1 = Probe<LOG2, WIDE>::template probe4<false>(cx.filter, cx.fold, cx.wa, cx.wb, cur);
+    // only windows that start inside the text (see stream_tile: chunks past the end are not queued at all)
+    if ((g << 4) + 16 > cx.nbytes) l1 &= (g << 4) < cx.nbytes ? (1u << static_cast<uint32_t>((cx.nbytes - (g << 4) + 3) >> 2)) - 1u : 0u;
     if (WIDE) {
       hits = l1;
     } else if (l1) {
@@ -376,7 +381,7 @@ __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, 
 #endif
 
 #if defined(HG_ABLATE) && HG_ABLATE == 1  // profiling aid: no window filter (results are wrong)
-    const bool any = (cur.x ^ cur.y ^ cur.z ^ cur.w) == 0x12345678u;
+    bool any = (cur.x ^ cur.y ^ cur.z ^ cur.w) == 0x12345678u;
 #else
     bool any;
     if constexpr (DENSE) {
@@ -386,6 +391,12 @@ __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, 
       any = Probe<LOG2, WIDE>::template probe4<true>(cx.filter, cx.fold, cx.wa, cx.wb, cur) != 0;
     }
 #endif
+
+    // The last, partial tile: lanes past the end of the text hold zeros, and a zero window can pass the filter (the case
+    // mask folds NUL onto ' ': a required literal of spaces, or a window value of zero).  Such a chunk holds no occurrence
+    // and must not reach the drain, whose neighbour reads assume a position inside the text.  (Round 1 shipped without
+    // this: the drain read up to a tile past the buffer, a GPU memory fault whenever that memory was not mapped.)
+    if constexpr (!FULL) any = any && ((chunk0 + static_cast<uint64_t>(it) * 64u) << 4) < nbytes;
 
     const uint64_t nlm = __builtin_amdgcn_ballot_w64(c != 0);
     const uint64_t multi = __builtin_amdgcn_ballot_w64(c > 1);  // a 16-byte chunk with several newlines: rare in logs
@@ -886,10 +897,15 @@ __global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
         const uint32_t lo = hg_ctz(sel), hi = 31u - hg_clz32(sel);
         inside = at + static_cast<int64_t>(lo) >= 0 && static_cast<uint64_t>(at + hi) < a.nbytes;
         if (inside) {
-          // pos and delta are multiples of 4; at < 0 only when every selected byte is past the first three: shift in zeros
-          uint32_t v;
-          if (at >= 0) v = *reinterpret_cast<const uint32_t *>(a.text + at);
-          else v = *reinterpret_cast<const uint32_t *>(a.text) << (8u * static_cast<uint32_t>(-at));
+          // dword-aligned windows: pos and delta are multiples of 4, one aligned load (it ends before the buffer's size
+          // rounded up to 4).  Byte-aligned windows (and at < 0, where only later bytes are selected): the selected bytes
+          // one by one, each of them inside the text.
+          uint32_t v = 0;
+          if (at >= 0 && (at & 3) == 0) {
+            v = *reinterpret_cast<const uint32_t *>(a.text + at);
+          } else {
+            for (uint32_t b = lo; b <= hi; b++) v |= static_cast<uint32_t>(a.text[at + static_cast<int64_t>(b)]) << (8u * b);
+          }
           key = (v | fold) & hg_disc_bytes(sel);
         }
       }

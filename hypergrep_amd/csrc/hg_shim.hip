@@ -42,10 +42,19 @@
 namespace {
 
 // ---------------------------------------------------------------- compiled-database cache
-// The reference recompiles the database for every file (hyperscanner.c:296); here identical pattern sets
-// share one compiled database (and its uploaded copy) for the life of the process.
+// The reference recompiles the database for every file (hyperscanner.c:296); here identical pattern sets share one
+// compiled database for the life of the process (at most kDbCacheMax sets, least recently used evicted; scanners keep
+// their own reference).  An entry is re-tuned once, on the first large file scanned with it (maybe_tune below).
+struct DbEntry {
+  std::shared_ptr<const HgDb> db;
+  bool tune_tried = false;
+  uint64_t stamp = 0;  // last use
+};
+constexpr size_t kDbCacheMax = 16;
 std::mutex g_mu;
-std::map<std::string, std::shared_ptr<HgDb>> g_dbs;
+std::map<std::string, DbEntry> g_dbs;
+uint64_t g_stamp = 0;
+std::atomic<uint64_t> g_cache_hits{0}, g_cache_misses{0}, g_tunes{0};
 
 std::string db_key(const char *const *patterns, const unsigned *flags, const unsigned *ids, unsigned n) {
   std::string k;
@@ -60,7 +69,8 @@ std::string db_key(const char *const *patterns, const unsigned *flags, const uns
   return k;
 }
 
-std::shared_ptr<HgDb> get_db(const char *const *patterns, const unsigned *flags, const unsigned *ids, unsigned n, std::string *err) {
+std::shared_ptr<const HgDb> get_db(const char *const *patterns, const unsigned *flags, const unsigned *ids, unsigned n, std::string *err,
+                                   std::string *key_out = nullptr) {
   if (!patterns || n == 0) {
     if (err) *err = "no patterns";
     return nullptr;
@@ -68,24 +78,93 @@ std::shared_ptr<HgDb> get_db(const char *const *patterns, const unsigned *flags,
   for (unsigned i = 0; i < n; i++)
     if (!patterns[i]) return nullptr;
   std::string key = db_key(patterns, flags, ids, n);
+  if (key_out) *key_out = key;
   {
     std::lock_guard<std::mutex> lock(g_mu);
     auto it = g_dbs.find(key);
-    if (it != g_dbs.end()) return it->second;
+    if (it != g_dbs.end()) {
+      it->second.stamp = ++g_stamp;
+      g_cache_hits++;
+      return it->second.db;
+    }
   }
+  g_cache_misses++;
   HgDb *raw = nullptr;
   int bad = -1;
   if (hgc_compile(patterns, flags, ids, n, &raw, err, &bad) != 0) return nullptr;
-  std::shared_ptr<HgDb> db(raw, [](HgDb *d) { hgc_free(d); });
+  std::shared_ptr<const HgDb> db(raw, [](const HgDb *d) { hgc_free(const_cast<HgDb *>(d)); });
   std::lock_guard<std::mutex> lock(g_mu);
-  if (g_dbs.size() >= 16) g_dbs.clear();  // scanners keep their own reference
-  g_dbs[key] = db;
+  auto it = g_dbs.find(key);
+  if (it != g_dbs.end()) {  // another thread compiled the same set meanwhile: keep one
+    it->second.stamp = ++g_stamp;
+    return it->second.db;
+  }
+  while (g_dbs.size() >= kDbCacheMax) {
+    auto oldest = g_dbs.begin();
+    for (auto j = g_dbs.begin(); j != g_dbs.end(); ++j)
+      if (j->second.stamp < oldest->second.stamp) oldest = j;
+    g_dbs.erase(oldest);
+  }
+  DbEntry e;
+  e.db = db;
+  e.stamp = ++g_stamp;
+  g_dbs.emplace(std::move(key), std::move(e));
   return db;
 }
 
+// The window prefilter picks, per required literal, WHICH four bytes of it the stream pass looks for.  Statically that is
+// a guess from byte frequencies of English-like logs; with a sample of the actual text it is the window that is rarest in
+// that text (bench.py's workload: first-level matches 4 % -> 1.2 % of dwords).  The file API does this by itself: the
+// first time a pattern set meets a file of at least HYPERGREP_TUNE_MIN_MB (default 32; 0 = never), 1 MiB of the first
+// ingest chunk (four spread pieces) is sampled on the host (~20 ms), the tuned copy replaces the cache entry, and this
+// and every later call of the pattern set scan with it.  Results never depend on it.
+size_t tune_min_bytes() {
+  static const size_t v = [] {
+    if (const char *env = std::getenv("HYPERGREP_TUNE_MIN_MB")) {
+      const long mb = std::atol(env);
+      if (mb >= 0 && mb <= (1 << 20)) return static_cast<size_t>(mb) << 20;
+    }
+    return static_cast<size_t>(32) << 20;
+  }();
+  return v;
+}
+std::shared_ptr<const HgDb> maybe_tune(const std::string &key, const std::shared_ptr<const HgDb> &db, const uint8_t *chunk, size_t nbytes) {
+  const size_t min_bytes = tune_min_bytes();
+  if (db->tuned || !db->nreal_factors || !min_bytes || nbytes < min_bytes) return db;
+  {
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_dbs.find(key);
+    if (it == g_dbs.end() || it->second.tune_tried) return it != g_dbs.end() && it->second.db->tuned ? it->second.db : db;
+    it->second.tune_tried = true;  // concurrent calls with the same set scan untuned this once
+  }
+  constexpr size_t kPiece = 256u << 10, kPieces = 4;
+  std::vector<uint8_t> sample;
+  sample.reserve(kPiece * kPieces);
+  for (size_t i = 0; i < kPieces; i++) {
+    const size_t at = (nbytes / kPieces * i) & ~static_cast<size_t>(15);
+    const size_t len = std::min(kPiece, nbytes - at);
+    sample.insert(sample.end(), chunk + at, chunk + at + len);
+  }
+  HgDb *raw = nullptr;
+  std::string err;
+  if (hgc_tune(db.get(), sample.data(), sample.size(), &raw, &err) != 0) return db;
+  std::shared_ptr<const HgDb> tuned(raw, [](const HgDb *d) { hgc_free(const_cast<HgDb *>(d)); });
+  g_tunes++;
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = g_dbs.find(key);
+  if (it != g_dbs.end()) it->second.db = tuned;
+  return tuned;
+}
+
 // ---------------------------------------------------------------- per-call device context, pooled
+// A context = streams + staging buffers (pinned slots, device text buffers) + the scanner of ONE pattern set.  At most
+// HYPERGREP_POOL contexts exist at a time (default 16: the reference's thread pool runs up to ncpu-1 scans, each of them
+// link-bound here); a call beyond that waits for one to come back.  Idle contexts are kept, most recently used last: a
+// call takes one that already holds its pattern set's scanner if there is one (the reference's use: one pattern set, many
+// files), else creates a new context while the bound allows, else re-binds the least recently used idle one (buffers and
+// streams stay, the scanner is replaced).
 struct Ctx {
-  std::shared_ptr<HgDb> db;
+  std::shared_ptr<const HgDb> db;  // pattern set of `sc`
   HgScanner *sc = nullptr;
   int device = 0;
   hipStream_t stream = nullptr;
@@ -99,7 +178,7 @@ struct Ctx {
   std::vector<HgHit> hits;
   std::vector<HgHitAux> aux;
   ~Ctx() {
-    if (sc) (void)hipSetDevice(device);
+    (void)hipSetDevice(device);
     delete sc;
     for (uint8_t *p : h_slot) hgmem::host_free(p, "h_slot");
     for (uint8_t *p : d_text) hgmem::dev_free(p, "d_text");
@@ -109,60 +188,121 @@ struct Ctx {
     if (stream) (void)hipStreamDestroy(stream);
   }
 };
-std::vector<Ctx *> g_idle;  // guarded by g_mu; intentionally never destroyed at exit (no HIP calls in static dtors)
+struct Pool {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<Ctx *> idle;  // least recently used first; intentionally never destroyed at exit (no HIP calls in static dtors)
+  size_t live = 0;          // contexts in existence (idle + checked out)
+  size_t cap = 16;
+  std::atomic<uint64_t> created{0}, reused{0}, rebound{0};
+  Pool() {
+    if (const char *env = std::getenv("HYPERGREP_POOL")) cap = static_cast<size_t>(std::max(1l, std::min(1024l, std::atol(env))));  // read once
+  }
+};
+Pool &pool() {
+  static Pool *p = new Pool();
+  return *p;
+}
 std::atomic<unsigned> g_next_device{0};
 
-Ctx *checkout(const std::shared_ptr<HgDb> &db, std::string *err) {
-  {
-    std::lock_guard<std::mutex> lock(g_mu);
-    for (size_t i = 0; i < g_idle.size(); i++)
-      if (g_idle[i]->db == db) {
-        Ctx *c = g_idle[i];
-        g_idle.erase(g_idle.begin() + i);
-        return c;
-      }
-  }
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
-    *err = "no HIP device available; hypergrep_amd has no CPU scan path";
-    return nullptr;
-  }
-  int device;
-  if (const char *env = std::getenv("HYPERGREP_DEVICE")) device = std::atoi(env) % ndev;
-  else device = static_cast<int>(g_next_device.fetch_add(1) % static_cast<unsigned>(ndev));  // files shard over the node's GPUs
-  auto c = std::make_unique<Ctx>();
-  c->db = db;
-  c->device = device;
-  if (HgScanner::create(db.get(), device, &c->sc, err) != HG_OK) return nullptr;
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_h2d[0], hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->ev_h2d[1], hipEventDisableTiming) != hipSuccess) {
-    *err = "hipStreamCreate failed";
-    return nullptr;
-  }
-  return c.release();
+}  // namespace
+// Device of the next Face B context when the node has `ndev` GPUs: HYPERGREP_DEVICE pins one, else files round-robin.
+extern "C" int hg_faceb_next_device(int ndev) {
+  if (ndev <= 0) return -1;
+  if (const char *env = std::getenv("HYPERGREP_DEVICE")) return std::abs(std::atoi(env)) % ndev;
+  return static_cast<int>(g_next_device.fetch_add(1) % static_cast<unsigned>(ndev));
 }
-void checkin(Ctx *c) {
-  // A few idle contexts are kept for reuse (one per pattern set in flight: the reference's thread pool scans many files with
-  // the SAME patterns); the oldest goes when a new one comes in.  Dozens of live contexts (a caller cycling through many
-  // pattern sets) are avoided on purpose: tools/fuzz_gpu.py hit a GPU memory fault with ~33 of them alive, root cause open.
-  size_t keep = 4;  // HYPERGREP_POOL overrides; 0 = none
-  if (const char *env = std::getenv("HYPERGREP_POOL")) keep = static_cast<size_t>(std::max(0l, std::atol(env)));
-  Ctx *evict = nullptr;
+// Counters of the caches above (tests, HYPERGREP_TRACE): database cache hits / misses / size, tunes, contexts created /
+// reused with their scanner / re-bound to another pattern set / alive.
+extern "C" void hg_faceb_stats(uint64_t out[8]) {
+  Pool &p = pool();
+  out[0] = g_cache_hits;
+  out[1] = g_cache_misses;
+  out[3] = g_tunes;
+  out[4] = p.created;
+  out[5] = p.reused;
+  out[6] = p.rebound;
   {
     std::lock_guard<std::mutex> lock(g_mu);
-    if (keep == 0) {
-      evict = c;
-    } else {
-      g_idle.push_back(c);
-      if (g_idle.size() > keep) {
-        evict = g_idle.front();
-        g_idle.erase(g_idle.begin());
+    out[2] = g_dbs.size();
+  }
+  std::lock_guard<std::mutex> lock(p.mu);
+  out[7] = p.live;
+}
+namespace {
+
+Ctx *checkout(const std::shared_ptr<const HgDb> &db, std::string *err) {
+  Pool &p = pool();
+  Ctx *c = nullptr;
+  {
+    std::unique_lock<std::mutex> lock(p.mu);
+    for (;;) {
+      for (size_t i = p.idle.size(); i-- > 0;)
+        if (p.idle[i]->db == db) {
+          c = p.idle[i];
+          p.idle.erase(p.idle.begin() + static_cast<long>(i));
+          p.reused++;
+          return c;
+        }
+      if (p.live < p.cap) {
+        p.live++;
+        break;  // create one (outside the lock)
       }
+      if (!p.idle.empty()) {
+        c = p.idle.front();
+        p.idle.erase(p.idle.begin());
+        p.rebound++;
+        return c;  // the caller replaces its scanner (ensure_scanner)
+      }
+      p.cv.wait(lock);
     }
   }
-  delete evict;  // (outside the lock: frees device memory)
+  auto fail = [&](const char *what) {
+    *err = what;
+    {
+      std::lock_guard<std::mutex> lock(p.mu);
+      p.live--;
+    }
+    p.cv.notify_one();
+    return static_cast<Ctx *>(nullptr);
+  };
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail("no HIP device available; hypergrep_amd has no CPU scan path");
+  auto fresh = std::make_unique<Ctx>();
+  fresh->device = hg_faceb_next_device(ndev);  // files shard over the node's GPUs
+  if (hipSetDevice(fresh->device) != hipSuccess || hipStreamCreateWithFlags(&fresh->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&fresh->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&fresh->ev_h2d[0], hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&fresh->ev_h2d[1], hipEventDisableTiming) != hipSuccess)
+    return fail("hipStreamCreate failed");
+  p.created++;
+  return fresh.release();
+}
+// healthy = the call ended without a device error: the context goes back for reuse.  After a HIP error the scanner's
+// streams and workspace are in an unknown state: everything is synchronised and destroyed instead.
+void checkin(Ctx *c, bool healthy) {
+  Pool &p = pool();
+  if (!healthy) {
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    delete c;
+    c = nullptr;
+  }
+  {
+    std::lock_guard<std::mutex> lock(p.mu);
+    if (c) p.idle.push_back(c);
+    else p.live--;
+  }
+  p.cv.notify_one();
+}
+// The context's scanner must be the one of `db` (created on first use; replaced when the context is re-bound).
+bool ensure_scanner(Ctx *c, const std::shared_ptr<const HgDb> &db, std::string *err) {
+  if (c->sc && c->db == db) return true;
+  if (hipSetDevice(c->device) != hipSuccess) return false;
+  delete c->sc;  // (hipFree synchronises the device: nothing of the old scanner is in flight afterwards)
+  c->sc = nullptr;
+  c->db = db;
+  return HgScanner::create(db, c->device, &c->sc, err) == HG_OK;
 }
 // slots: pinned buffers needed (1 for a file that fits one chunk, else all)
 bool ensure_buffers(Ctx *c, size_t cap, int slots) {
@@ -182,8 +322,10 @@ bool ensure_buffers(Ctx *c, size_t cap, int slots) {
     }
     c->d_cap = cap;
   }
+  // + 32: the kernels may read the text up to its size rounded up to 16 bytes, and the verify pass's byte-aligned
+  // discriminator load up to 3 bytes further (hg_verify_kernel)
   for (int i = 0; i < (slots > 1 ? Ctx::kDevBufs : 1); i++)
-    if (!c->d_text[i] && hgmem::dev_alloc(&c->d_text[i], c->d_cap + 16, "d_text") != hipSuccess) return false;
+    if (!c->d_text[i] && hgmem::dev_alloc(&c->d_text[i], c->d_cap + 32, "d_text") != hipSuccess) return false;
   return true;
 }
 
@@ -420,25 +562,29 @@ extern "C" int hyperscan(char *file_name, const char *const *patterns, const uns
   Ring ring;
   if (!ring.init(buffer_count, buffer_size, on_event)) return HYPERSCANNER_COMPILE_MEM;
 
-  std::string err;
-  std::shared_ptr<HgDb> db = get_db(patterns, pattern_flags, pattern_ids, elements, &err);
+  std::string err, db_key_str;
+  std::shared_ptr<const HgDb> db = get_db(patterns, pattern_flags, pattern_ids, elements, &err, &db_key_str);
   if (!db) {
     std::fprintf(stderr, "ERROR: Unable to create database. Exiting.\n");
     return HYPERSCANNER_DB;
   }
+  // the file is opened before any device resource is taken: a missing file is HYPERSCANNER_GZ_OPEN with or without a GPU
+  // (the reference's scratch allocation cannot fail for want of a device; its order is database, scratch, file)
+  Reader in;
+  if (!file_name || !in.open(file_name)) return HYPERSCANNER_GZ_OPEN;
+  if (buffer_size < 2) return 0;  // gzgets(len <= 1) returns NULL at once: nothing is scanned (hyperscanner.c:199)
+
   Ctx *ctx = checkout(db, &err);
   if (!ctx) {
     std::fprintf(stderr, "ERROR: Unable to allocate scratch space. Exiting. (%s)\n", err.c_str());
     return HYPERSCANNER_SCRATCH;
   }
+  bool healthy = true;  // false after a device error: the context is destroyed, not pooled
   struct Return {
     Ctx *c;
-    ~Return() { checkin(c); }
-  } ret_guard{ctx};
-
-  Reader in;
-  if (!file_name || !in.open(file_name)) return HYPERSCANNER_GZ_OPEN;
-  if (buffer_size < 2) return 0;  // gzgets(len <= 1) returns NULL at once: nothing is scanned (hyperscanner.c:199)
+    bool *healthy;
+    ~Return() { checkin(c, *healthy); }
+  } ret_guard{ctx, &healthy};
 
   const uint64_t bs1 = static_cast<uint64_t>(buffer_size) - 1;
   size_t cap = chunk_bytes();
@@ -449,6 +595,7 @@ extern "C" int hyperscan(char *file_name, const char *const *patterns, const uns
   const int nslots = one_chunk ? 1 : Ctx::kSlots;
   if (hipSetDevice(ctx->device) != hipSuccess || !ensure_buffers(ctx, cap, nslots)) {
     std::fprintf(stderr, "ERROR: Unable to allocate scratch space. Exiting. (device buffers)\n");
+    healthy = false;
     return HYPERSCANNER_SCRATCH;
   }
 
@@ -463,7 +610,7 @@ extern "C" int hyperscan(char *file_name, const char *const *patterns, const uns
   const bool trace = std::getenv("HYPERGREP_TRACE") != nullptr;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_call = now();
-  double t_read = 0, t_wait_slot = 0, t_scan = 0, t_deliver = 0;  // reader: filling slots; consumer: waiting for a slot, copy + scan + hit copy, ring + callbacks
+  double t_read = 0, t_wait_slot = 0, t_scan = 0, t_deliver = 0, t_setup = 0;  // reader: filling slots; consumer: waiting for a slot, copy + scan + hit copy, ring + callbacks
   uint64_t bytes_in = 0;
   std::mutex mu;
   std::condition_variable cv;
@@ -546,6 +693,17 @@ extern "C" int hyperscan(char *file_name, const char *const *patterns, const uns
     const uint8_t *host = ctx->h_slot[sl];
     const size_t cut = s.cut;
     const bool last = s.last;
+    if (k == 0) {  // the pattern set's first large file picks the prefilter windows from this text (maybe_tune); then the scanner
+      const double t0 = now();
+      if (cut) db = maybe_tune(db_key_str, db, host, cut);
+      if (!ensure_scanner(ctx, db, &err)) {
+        std::fprintf(stderr, "ERROR: Unable to allocate scratch space. Exiting. (%s)\n", err.c_str());
+        rc = HYPERSCANNER_SCRATCH;
+        healthy = false;
+        break;
+      }
+      t_setup = now() - t0;
+    }
     if (cut) {
       const double t_begin = now();
       bytes_in += cut;
@@ -553,6 +711,7 @@ extern "C" int hyperscan(char *file_name, const char *const *patterns, const uns
       if (!issue_copy(k) || (next_ready && !issue_copy(k + 1)) ||  // the next chunk travels while this one is scanned
           hipStreamWaitEvent(ctx->stream, ctx->ev_h2d[k % Ctx::kDevBufs], 0) != hipSuccess) {
         rc = HYPERSCANNER_SCAN;
+        healthy = false;
         break;
       }
       HgScanOutput out{};
@@ -560,6 +719,7 @@ extern "C" int hyperscan(char *file_name, const char *const *patterns, const uns
       if (src != HG_OK) {
         std::fprintf(stderr, "ERROR: Unable to scan buffer. Exiting. (%s)\n", ctx->sc->last_error().c_str());
         rc = HYPERSCANNER_SCAN;
+        healthy = false;
         break;
       }
       ctx->hits.resize(out.n_hits);
@@ -569,6 +729,7 @@ extern "C" int hyperscan(char *file_name, const char *const *patterns, const uns
             hipMemcpyAsync(ctx->aux.data(), out.d_aux, out.n_hits * sizeof(HgHitAux), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipStreamSynchronize(ctx->stream) != hipSuccess) {
           rc = HYPERSCANNER_SCAN;
+          healthy = false;
           break;
         }
       }
@@ -609,7 +770,8 @@ extern "C" int hyperscan(char *file_name, const char *const *patterns, const uns
   (void)hipStreamSynchronize(ctx->copy_stream);  // a copy issued ahead may still be in flight
   ring.flush();
   if (trace)
-    std::fprintf(stderr, "[hypergrep_amd] %s: %.1f MiB in %.4f s; reader filling slots %.4f s; consumer: waiting for data %.4f s, copy + scan %.4f s, delivering %llu hits %.4f s\n",
-                 file_name, bytes_in / 1048576.0, now() - t_call, t_read, t_wait_slot, t_scan, static_cast<unsigned long long>(ring.delivered), t_deliver);
+    std::fprintf(stderr, "[hypergrep_amd] %s: %.1f MiB in %.4f s; reader filling slots %.4f s; consumer: waiting for data %.4f s, window tuning + scanner %.4f s (%s), copy + scan %.4f s, delivering %llu hits %.4f s\n",
+                 file_name, bytes_in / 1048576.0, now() - t_call, t_read, t_wait_slot, t_setup, db->tuned ? "tuned windows" : "static windows", t_scan,
+                 static_cast<unsigned long long>(ring.delivered), t_deliver);
   return rc;
 }

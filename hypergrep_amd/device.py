@@ -64,6 +64,13 @@ def lib() -> ctypes.CDLL:
         l.hg_copy_hits_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
         l.hg_synth_device.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(HgSynthSpec), ctypes.c_int, ctypes.c_void_p]
         l.hg_synth_host.argtypes = [ctypes.c_char_p, ctypes.c_uint64, ctypes.POINTER(HgSynthSpec)]
+        l.hg_debug_alloc_guarded.argtypes = [ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]
+        l.hg_debug_free_guarded.argtypes = [ctypes.c_void_p]
+        l.hg_debug_free_guarded.restype = None
+        l.hg_debug_upload.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64]
+        l.hg_faceb_next_device.argtypes = [ctypes.c_int]
+        l.hg_faceb_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
+        l.hg_faceb_stats.restype = None
         _configured = True
     return l
 
@@ -192,3 +199,43 @@ def synth_host(nbytes: int, seed: int, needles, hit_per_million: int, first_bloc
     if rc != 0:
         raise RuntimeError(f"hg_synth_host failed ({rc})")
     return buf.raw
+
+
+class GuardedBuffer:
+    """Device memory holding `data` whose end (rounded up to 16 bytes) is followed by unmapped address space
+    (hg_debug_alloc_guarded): a kernel that reads past the text faults instead of passing silently."""
+
+    def __init__(self, data: bytes, device: int = 0):
+        self.nbytes = len(data)
+        self._ptr = ctypes.c_void_p()
+        self._guard = ctypes.c_void_p()
+        rc = lib().hg_debug_alloc_guarded(max(self.nbytes, 1), device, ctypes.byref(self._ptr), ctypes.byref(self._guard))
+        if rc != 0:
+            raise DeviceError(f"hg_debug_alloc_guarded failed ({rc})")
+        if self.nbytes and lib().hg_debug_upload(self._ptr, data, self.nbytes) != 0:
+            raise DeviceError("hg_debug_upload failed")
+
+    @property
+    def ptr(self) -> int:
+        return self._ptr.value
+
+    def free(self) -> None:
+        if getattr(self, "_guard", None):
+            lib().hg_debug_free_guarded(self._guard)
+            self._guard = None
+
+    def __del__(self):
+        if lib is not None:
+            self.free()
+
+
+def faceb_stats() -> dict:
+    """Counters of the file API's caches (hg_faceb_stats)."""
+    out = (ctypes.c_uint64 * 8)()
+    lib().hg_faceb_stats(out)
+    names = ("db_cache_hits", "db_cache_misses", "db_cache_entries", "tunes", "contexts_created", "contexts_reused", "contexts_rebound", "contexts_alive")
+    return dict(zip(names, (int(v) for v in out)))
+
+
+def faceb_next_device(ndev: int) -> int:
+    return lib().hg_faceb_next_device(ndev)

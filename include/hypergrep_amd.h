@@ -163,8 +163,9 @@ typedef struct hg_db_info {
 int hg_db_compile(const char *const *expressions, const unsigned int *flags, const unsigned int *ids,
                   unsigned int n, hg_database_t **db, char *err, size_t errlen);
 /* Optional: re-select the literal windows of the prefilter using byte statistics of a host-side text sample (any
- * prefix of what will be scanned) and rebuild the filter tables.  Never changes results, only how often the slower
- * stages run.  Call before hg_scanner_create. */
+ * part of what will be scanned) and rebuild the filter tables.  Never changes results, only how often the slower
+ * stages run.  The tuned tables are built aside and swapped in on success: scanners created BEFORE the call keep the
+ * tables they were created with (still valid), scanners created after it use the tuned ones; on failure nothing changes. */
 int hg_db_tune(hg_database_t *db, const void *sample, size_t nbytes);
 void hg_db_release(hg_database_t *db);
 int hg_db_info(const hg_database_t *db, hg_db_info_t *info);
@@ -198,6 +199,19 @@ typedef struct hg_synth_spec {
 } hg_synth_spec_t;
 int hg_synth_device(void *d_text, uint64_t nbytes, const hg_synth_spec_t *spec, int device, void *stream);
 int hg_synth_host(uint8_t *text, uint64_t nbytes, const hg_synth_spec_t *spec);
+
+/* ---- diagnostics (tests, tools) ------------------------------------------------------------------------------------
+ * A device buffer of `nbytes` (rounded up to 16) whose end is followed by reserved, unmapped address space: a read or
+ * write past it is a GPU memory fault instead of a silent pass.  The parity tests run on such buffers so that an
+ * over-read in any kernel fails where it happens.  hg_debug_upload: a blocking host-to-device copy into it. */
+int hg_debug_alloc_guarded(uint64_t nbytes, int device, void **d_ptr, void **guard_handle);
+void hg_debug_free_guarded(void *guard_handle);
+int hg_debug_upload(void *d_dst, const void *src, uint64_t nbytes);
+/* Face B bookkeeping, for tests and HYPERGREP_TRACE: the device the next scan context would be created on for a node of
+ * `ndev` GPUs (HYPERGREP_DEVICE pins one, otherwise files round-robin; advances the round-robin), and the cache counters
+ * {database cache hits, misses, entries, window tunings, contexts created, reused, re-bound to another pattern set, alive}. */
+int hg_faceb_next_device(int ndev);
+void hg_faceb_stats(uint64_t out[8]);
 
 #ifdef __cplusplus
 }

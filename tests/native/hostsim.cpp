@@ -36,9 +36,14 @@ void *hgsim_compile(const char *const *exprs, const unsigned *flags, const unsig
   }
   return db;
 }
-int hgsim_tune(void *h, const uint8_t *sample, size_t n) {
+int hgsim_tune(void *h, const uint8_t *sample, size_t n) {  // the handle keeps its identity: the tuned copy's tables move in
   std::string e;
-  return hgc_tune(static_cast<HgDb *>(h), sample, n, &e);
+  HgDb *tuned = nullptr;
+  int rc = hgc_tune(static_cast<const HgDb *>(h), sample, n, &tuned, &e);
+  if (rc != 0) return rc;
+  *static_cast<HgDb *>(h) = std::move(*tuned);
+  hgc_free(tuned);
+  return 0;
 }
 void hgsim_free(void *h) { hgc_free(static_cast<HgDb *>(h)); }
 

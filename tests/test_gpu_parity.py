@@ -853,3 +853,35 @@ def test_face_a_artefact_under_the_shim_call_order(torch_cuda, tmp_path):
     # a rejected expression: HYPERSCANNER_COMPILE (2) through the same sequence, error record freed
     bad = subprocess.run([exe, product, cases[0][0], "64", "--", "14", "0", "(?<=a)b"], capture_output=True, text=True, timeout=60)
     assert bad.returncode == 2 and "compile failed" in bad.stderr
+
+
+# ------------------------------------------------------------------ regressions for round 1's GPU memory fault
+def _run_gpu_cases(mode: str, env: dict | None = None, timeout: int = 600) -> dict:
+    import subprocess
+    import sys
+
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run([sys.executable, os.path.join(HERE, "gpu_cases.py"), mode], capture_output=True, text=True, timeout=timeout, env=e)
+    assert out.returncode == 0, f"gpu_cases.py {mode} failed (rc {out.returncode}):\n{out.stdout[-2000:]}\n{out.stderr[-3000:]}"
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def test_no_kernel_reads_past_the_text(torch_cuda):
+    """Parity cases on GUARDED text buffers (the address space right after the text is unmapped): zero bytes past a partial
+    last tile that look like spaces or like a zero window, byte-aligned and dword-aligned windows, filters of every size
+    class, always-on patterns, small scan buffers.  Round 1's fault was the drain of the stream kernel reading neighbour
+    bytes of window positions PAST the text (tests/gpu_cases.py::guarded_cases has the case); in a child process, because a
+    violation is a GPU memory fault."""
+    res = _run_gpu_cases("guarded")
+    assert res["ok"] and res["cases"] >= 70, res
+
+
+def test_many_pattern_sets_through_the_file_api(torch_cuda):
+    """48 distinct pattern sets through hyperscan() in ONE process, once with room for every context to stay alive (the
+    state round 1's fault needed) and once with a pool of 4, which makes contexts change their pattern set (scanner
+    replaced, staging buffers kept)."""
+    res = _run_gpu_cases("many-sets", {"HYPERGREP_POOL": "64"})
+    assert res["ok"] and res["sets"] == 48 and res["contexts_alive"] >= 40, res
+    res = _run_gpu_cases("many-sets", {"HYPERGREP_POOL": "4"})
+    assert res["ok"] and res["contexts_alive"] <= 4 and res["contexts_rebound"] >= 40, res
