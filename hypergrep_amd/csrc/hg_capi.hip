@@ -197,6 +197,12 @@ int hg_debug_upload(void *d_dst, const void *src, uint64_t nbytes) {
   return hipMemcpy(d_dst, src, nbytes, hipMemcpyHostToDevice) == hipSuccess ? HG_OK : HG_ERR_HIP;
 }
 
+int hg_debug_download(void *dst, const void *d_src, uint64_t nbytes) {
+  if (!nbytes) return HG_OK;
+  if (!dst || !d_src) return HG_ERR_ARG;
+  return hipMemcpy(dst, d_src, nbytes, hipMemcpyDeviceToHost) == hipSuccess ? HG_OK : HG_ERR_HIP;
+}
+
 }  // extern "C"
 
 // ---------------------------------------------------------------- synthetic log

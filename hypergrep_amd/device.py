@@ -68,6 +68,7 @@ def lib() -> ctypes.CDLL:
         l.hg_debug_free_guarded.argtypes = [ctypes.c_void_p]
         l.hg_debug_free_guarded.restype = None
         l.hg_debug_upload.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint64]
+        l.hg_debug_download.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_uint64]
         l.hg_faceb_next_device.argtypes = [ctypes.c_int]
         l.hg_faceb_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)]
         l.hg_faceb_stats.restype = None
@@ -201,23 +202,36 @@ def synth_host(nbytes: int, seed: int, needles, hit_per_million: int, first_bloc
     return buf.raw
 
 
-class GuardedBuffer:
-    """Device memory holding `data` whose end (rounded up to 16 bytes) is followed by unmapped address space
-    (hg_debug_alloc_guarded): a kernel that reads past the text faults instead of passing silently."""
+class GuardedArena:
+    """Device memory whose END is followed by unmapped address space (hg_debug_alloc_guarded).  place(data) puts the bytes
+    so that they end (rounded up to 16) exactly at that edge and returns the device pointer: a kernel that reads past the
+    text faults instead of passing silently.  One arena serves many texts — it is mapped once (re-mapping the same
+    addresses per text showed stale reads on this stack)."""
 
-    def __init__(self, data: bytes, device: int = 0):
-        self.nbytes = len(data)
+    def __init__(self, capacity: int, device: int = 0):
+        self.capacity = (max(capacity, 16) + 15) & ~15
         self._ptr = ctypes.c_void_p()
         self._guard = ctypes.c_void_p()
-        rc = lib().hg_debug_alloc_guarded(max(self.nbytes, 1), device, ctypes.byref(self._ptr), ctypes.byref(self._guard))
+        rc = lib().hg_debug_alloc_guarded(self.capacity, device, ctypes.byref(self._ptr), ctypes.byref(self._guard))
         if rc != 0:
             raise DeviceError(f"hg_debug_alloc_guarded failed ({rc})")
-        if self.nbytes and lib().hg_debug_upload(self._ptr, data, self.nbytes) != 0:
-            raise DeviceError("hg_debug_upload failed")
 
-    @property
-    def ptr(self) -> int:
-        return self._ptr.value
+    def place(self, data: bytes) -> int:
+        usable = (len(data) + 15) & ~15
+        if usable > self.capacity:
+            raise ValueError("text larger than the arena")
+        ptr = self._ptr.value + self.capacity - usable
+        if data and lib().hg_debug_upload(ctypes.c_void_p(ptr), data, len(data)) != 0:
+            raise DeviceError("hg_debug_upload failed")
+        return ptr
+
+    def tail(self, nbytes: int) -> bytes:
+        """The bytes between the end of a text of `nbytes` placed last and the edge (whatever the memory held before)."""
+        n = ((nbytes + 15) & ~15) - nbytes
+        out = ctypes.create_string_buffer(max(n, 1))
+        if n and lib().hg_debug_download(out, ctypes.c_void_p(self._ptr.value + self.capacity - n), n) != 0:
+            raise DeviceError("hg_debug_download failed")
+        return out.raw[:n]
 
     def free(self) -> None:
         if getattr(self, "_guard", None):

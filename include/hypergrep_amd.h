@@ -203,10 +203,11 @@ int hg_synth_host(uint8_t *text, uint64_t nbytes, const hg_synth_spec_t *spec);
 /* ---- diagnostics (tests, tools) ------------------------------------------------------------------------------------
  * A device buffer of `nbytes` (rounded up to 16) whose end is followed by reserved, unmapped address space: a read or
  * write past it is a GPU memory fault instead of a silent pass.  The parity tests run on such buffers so that an
- * over-read in any kernel fails where it happens.  hg_debug_upload: a blocking host-to-device copy into it. */
+ * over-read in any kernel fails where it happens.  hg_debug_upload / hg_debug_download: blocking copies to / from it. */
 int hg_debug_alloc_guarded(uint64_t nbytes, int device, void **d_ptr, void **guard_handle);
 void hg_debug_free_guarded(void *guard_handle);
 int hg_debug_upload(void *d_dst, const void *src, uint64_t nbytes);
+int hg_debug_download(void *dst, const void *d_src, uint64_t nbytes);
 /* Face B bookkeeping, for tests and HYPERGREP_TRACE: the device the next scan context would be created on for a node of
  * `ndev` GPUs (HYPERGREP_DEVICE pins one, otherwise files round-robin; advances the round-robin), and the cache counters
  * {database cache hits, misses, entries, window tunings, contexts created, reused, re-bound to another pattern set, alive}. */

@@ -67,7 +67,9 @@ def run_guarded() -> dict:
     from hypergrep_amd import device
 
     n = 0
+    bad = []
     compiled = {}
+    arena = device.GuardedArena(1 << 20)
     for name, text, pats, flags, ids, bs in guarded_cases():
         want, nlines = oracle_hits(text, pats, flags, ids, buffer_size=bs)
         key = (tuple(pats), tuple(flags or ()), tuple(ids or ()))
@@ -75,16 +77,14 @@ def run_guarded() -> dict:
             db = device.Database(pats, flags=flags, ids=ids)
             compiled[key] = (db, device.Scanner(db, 0))
         db, sc = compiled[key]
-        buf = device.GuardedBuffer(text)
-        try:
-            stats = sc.scan(buf.ptr, len(text), buffer_size=bs)
-            got = sorted(sc.hits())
-        finally:
-            buf.free()
+        stats = sc.scan(arena.place(text), len(text), buffer_size=bs)
+        got = sorted(sc.hits())
+        tail = arena.tail(len(text))
         if got != want or stats.n_lines != nlines:
-            return {"ok": False, "case": name, "got": len(got), "want": len(want), "lines": [stats.n_lines, nlines]}
+            bad.append({"case": name, "got": len(got), "want": len(want), "lines": [stats.n_lines, nlines], "bytes_after_text": tail.hex(),
+                        "extra": sorted(set(got) - set(want))[:6], "missing": sorted(set(want) - set(got))[:6]})
         n += 1
-    return {"ok": True, "cases": n}
+    return {"ok": not bad, "cases": n, "failed": bad[:8]}
 
 
 def run_many_sets() -> dict:
