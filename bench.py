@@ -44,6 +44,10 @@ def main() -> None:
     import torch
     import torch.distributed as dist
 
+    if os.environ.get("HG_LIB"):  # experiment builds (hypergrep_amd/build.py HG_BUILD_OUT)
+        import hypergrep_amd
+
+        hypergrep_amd.configure_libraries(libhs=os.path.abspath(os.environ["HG_LIB"]))
     from hypergrep_amd import benchspec, device, shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

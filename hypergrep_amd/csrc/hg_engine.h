@@ -22,6 +22,10 @@ struct HgDeferred {
 };
 enum { HG_CNT_CANDS = 0, HG_CNT_HITS = 1, HG_CNT_CAND_NEED = 2, HG_CNT_HIT_NEED = 3, HG_CNT_DEFER_NEED = 4, HG_CNT_WORDS = 8 };
 
+// Bucketed finalize (hg_fin_*): buckets of the final ordering and the largest bucket one wave sorts in LDS.
+constexpr uint32_t HG_FIN_MAX_BUCKETS = 1u << 16;
+constexpr uint32_t HG_FIN_BUCKET_CAP = 4096;
+
 // Threads of a confirm block: its LDS (the per-lane follow tables of the one-word automata, 128 B per lane) decides how many
 // fit on a CU next to the stream pass.
 #ifndef HG_CONFIRM_THREADS
@@ -73,8 +77,14 @@ struct HgConfirmArgs {
   uint32_t list_spread[HG_CONFIRM_MODES];  // automaton modes: lists per pattern (few patterns: each is spread over several lists)
   uint32_t cand_seg_cap, hit_cap, hit_seg_cap, defer_shard_cap;
   uint32_t hit_direct;  // 1: a block whose staging segment is full appends to the compact array itself (HitSink)
+  // Bucketed emission (the default, bucket_cap != 0): a hit goes straight into the region of the bucket its line starts in
+  // (bucket = aux.start >> bucket_shift, bucket_cap records each, bucket_fill = records so far); the finalize kernels
+  // (hg_fin_*) then sort every bucket on its own.  bucket_cap == 0: the compact array + library sort (HitSink, flush_hits).
+  uint32_t bucket_shift, bucket_cap;
+  uint32_t *bucket_fill;
   uint32_t *counters;
 };
+constexpr uint32_t HG_HIT_SINGLE_BIT = 0x80000000u;  // raw bucketed records: bit 31 of `to` = the expression has HS_FLAG_SINGLEMATCH (`to` < 2^31)
 
 struct HgScanOutput {
   uint64_t n_hits;       // final (ordered, de-duplicated) hits
@@ -149,9 +159,10 @@ class HgScanner {
   static constexpr int kMaxChunks = 16;
   hipStream_t side_stream_ = nullptr;
   hipEvent_t ev_k1_begin_[kMaxChunks] = {}, ev_k1_end_[kMaxChunks] = {}, ev_side_done_[kMaxChunks] = {};
-  hipStream_t fin_stream_ = nullptr;   // early sort of the first chunks' hits (chunked pipeline)
-  hipEvent_t ev_fin_done_ = nullptr;
-  uint32_t *h_early_ = nullptr;        // pinned: counters after the last-but-one chunk's side passes
+  // bucketed emission + finalize (hg_fin_*): records per bucket / kept counts -> output positions / {kept, raw} totals;
+  // fin_fallback_: a bucket outgrew what one block sorts, the compact array + library sort is used from then on
+  uint32_t *d_fin_fill_ = nullptr, *d_fin_kept_ = nullptr, *d_fin_total_ = nullptr, *d_fin_big_ = nullptr;
+  bool fin_fallback_ = false;
   uint32_t *d_seg_count2_ = nullptr;  // second set for double buffering
   HgCand *d_cands2_ = nullptr;
 };

@@ -28,6 +28,13 @@ __global__ void hg_always_on_fast_kernel(HgConfirmArgs a);
 __global__ void hg_always_on_finish_kernel(HgConfirmArgs a);
 __global__ void hg_block_mark_kernel(HgConfirmArgs a, uint32_t *pattern_flags);
 __global__ void hg_block_scan_kernel(HgConfirmArgs a, const uint32_t *pattern_flags);
+__global__ void hg_fin_sort_small_kernel(const HgHit *hits, uint32_t *idx, const uint32_t *fill, uint32_t b_lo, uint32_t b_hi, uint32_t cap, uint32_t id_bits,
+                                         uint32_t to_bits, uint32_t *kept_count, uint32_t *raw_total, uint32_t *big_list, uint32_t *big_count);
+__global__ void hg_fin_sort_big_kernel(const HgHit *hits, uint32_t *idx, const uint32_t *fill, const uint32_t *big_list, const uint32_t *big_count, uint32_t cap,
+                                       uint32_t id_bits, uint32_t to_bits, uint32_t *kept_count, uint32_t *raw_total, uint32_t *overflow);
+__global__ void hg_fin_scan_kernel(uint32_t *kept_count, uint32_t b_lo, uint32_t b_hi, uint32_t *total);
+__global__ void hg_fin_gather_kernel(const HgHit *hits, const HgHitAux *aux, const uint32_t *idx, const uint32_t *kept_base, const uint32_t *total, uint32_t b_lo,
+                                     uint32_t b_hi, uint32_t cap, HgHit *oh, HgHitAux *oa);
 __global__ void hg_key_kernel(const HgHit *hits, const HgHitAux *aux, const HgPattern *patterns, uint32_t n, uint64_t *key, uint32_t *idx);
 __global__ void hg_line_key_kernel(const HgHit *hits, const uint32_t *perm, uint32_t n, uint64_t *key);
 __global__ void hg_offset_kernel(uint32_t *idx, uint32_t n, uint32_t add);
@@ -123,9 +130,10 @@ int HgScanner::create(std::shared_ptr<const HgDb> db, int device, HgScanner **ou
   HG_TRY(hgmem::host_alloc(&s->h_final_, sizeof(HgTileBase), "h_final_"), "alloc pinned");
   for (auto &ev : s->ev_) HG_TRY(hipEventCreate(&ev), "hipEventCreate");
   HG_TRY(hipStreamCreateWithFlags(&s->side_stream_, hipStreamNonBlocking), "hipStreamCreate");
-  HG_TRY(hipStreamCreateWithFlags(&s->fin_stream_, hipStreamNonBlocking), "hipStreamCreate");
-  HG_TRY(hipEventCreateWithFlags(&s->ev_fin_done_, hipEventDisableTiming), "hipEventCreate");
-  HG_TRY(hgmem::host_alloc(&s->h_early_, HG_CNT_WORDS * 4, "h_early_"), "alloc pinned");
+  HG_TRY(hgmem::dev_alloc(&s->d_fin_fill_, HG_FIN_MAX_BUCKETS * 4, "d_fin_fill_"), "alloc finalize buckets");
+  HG_TRY(hgmem::dev_alloc(&s->d_fin_kept_, HG_FIN_MAX_BUCKETS * 4, "d_fin_kept_"), "alloc finalize buckets");
+  HG_TRY(hgmem::dev_alloc(&s->d_fin_total_, 16, "d_fin_total_"), "alloc finalize buckets");
+  HG_TRY(hgmem::dev_alloc(&s->d_fin_big_, HG_FIN_MAX_BUCKETS * 4, "d_fin_big_"), "alloc finalize buckets");
   // (the per-chunk events of the two-stream pipeline are created by the first scan that is large enough to use it: a
   // process that keeps dozens of scanners for small files would otherwise hold thousands of events for nothing)
 #undef HG_TRY
@@ -149,9 +157,10 @@ HgScanner::~HgScanner() {
     if (ev_side_done_[i]) (void)hipEventDestroy(ev_side_done_[i]);
   }
   if (side_stream_) (void)hipStreamDestroy(side_stream_);
-  if (fin_stream_) (void)hipStreamDestroy(fin_stream_);
-  if (ev_fin_done_) (void)hipEventDestroy(ev_fin_done_);
-  hgmem::host_free(h_early_, "h_early_");
+  hgmem::dev_free(d_fin_fill_, "d_fin_fill_");
+  hgmem::dev_free(d_fin_kept_, "d_fin_kept_");
+  hgmem::dev_free(d_fin_total_, "d_fin_total_");
+  hgmem::dev_free(d_fin_big_, "d_fin_big_");
 }
 
 int HgScanner::alloc_cands(uint64_t n) {
@@ -229,6 +238,26 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   if (fail((call), what)) return HG_ERR_HIP;
   HG_TRY(hipMemsetAsync(d_counters_, 0, HG_CNT_WORDS * 4, stream), "memset counters");
   HG_TRY(hipEventRecord(ev_[0], stream), "event");
+  // Bucketed emission + finalize (hg_fin_*): buckets of 2^fin_shift text bytes (4 KiB at least) by line start, at most
+  // HG_FIN_MAX_BUCKETS of them, each a region of fin_cap records of the hit arrays.  The packed sort key must hold the line
+  // field before the line count is known: it is sized for one line per byte.
+  const uint32_t id_bits = bits_for(static_cast<uint64_t>(db_->max_id) + 1), to_bits = bits_for(bs1 + 1);
+  uint32_t fin_shift = 12, fin_nb = 1;
+  if (nbytes) {
+    while (((nbytes - 1) >> fin_shift) >= HG_FIN_MAX_BUCKETS) fin_shift++;
+    fin_nb = static_cast<uint32_t>((nbytes - 1) >> fin_shift) + 1;
+  }
+  const uint32_t fin_cap = hit_cap_ / fin_nb;
+  const bool bucketed = ntiles && fin_cap && bits_for(line_base + nbytes + 1) + id_bits + to_bits + 1 <= 64 && !fin_fallback_ && !std::getenv("HG_NO_BUCKET_FINALIZE");
+  uint32_t fin_done = 0;  // buckets finalized so far
+  // one finalize after the last chunk: per chunk (beside the stream pass of the next one) it slowed the stream pass by more
+  // than it took off the tail (measured: 8.33 vs 7.93 ms per 32 GiB); HG_FIN_PER_CHUNK=1 brings that variant back
+  const bool fin_at_end = std::getenv("HG_FIN_PER_CHUNK") == nullptr;
+  if (bucketed) {
+    HG_TRY(hipMemsetAsync(d_fin_fill_, 0, fin_nb * 4, stream), "memset buckets");
+    HG_TRY(hipMemsetAsync(d_fin_total_, 0, 16, stream), "memset buckets");
+    HG_TRY(hipMemsetAsync(d_selected_, 0, 8, stream), "memset flags");
+  }
 
   // Chunked pipeline (line mode, large buffers): the text is cut into tile-aligned chunks; the stream pass of chunk c+1
   // runs on the caller's stream while tile scan + verify + confirm of chunk c run on a side stream.  The stream pass
@@ -364,6 +393,9 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       ca.cand_seg_cap = sa.cand_seg_cap;
       ca.hit_cap = hit_cap_;
       ca.hit_direct = hit_direct_ ? 1u : 0u;
+      ca.bucket_cap = bucketed ? fin_cap : 0u;
+      ca.bucket_shift = fin_shift;
+      ca.bucket_fill = d_fin_fill_;
       ca.counters = d_counters_;
       if (block_mode) {
         HG_TRY(hipMemsetAsync(d_pflags_, 0, db_->patterns.size() * 4, side), "memset pattern flags");
@@ -425,7 +457,27 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
           HG_TRY(hipGetLastError(), "hg_always_on_kernel launch");
         }
       }
-      if (piped && c + 2 == nchunks) HG_TRY(hipMemcpyAsync(h_early_, d_counters_, HG_CNT_WORDS * 4, hipMemcpyDeviceToHost, side), "copy counters");
+      if (bucketed) {
+        // the buckets no later chunk can add to: a hit found past this chunk's end lies in a piece that starts less than bs1
+        // bytes before it
+        const uint64_t end_byte = std::min<uint64_t>(t1 << HG_TILE_SHIFT, nbytes);
+        uint32_t lim = fin_nb;
+        if (c + 1 < nchunks) lim = fin_at_end ? 0u : static_cast<uint32_t>(std::min<uint64_t>((end_byte > bs1 ? end_byte - bs1 : 0) >> fin_shift, fin_nb));
+        if (lim > fin_done) {
+          const uint32_t nbk = lim - fin_done;
+          const uint32_t cu = static_cast<uint32_t>(num_cus_);
+          HG_TRY(hipMemsetAsync(d_fin_total_ + 2, 0, 4, side), "memset work list");  // (big buckets of this range)
+          hipLaunchKernelGGL(hg_fin_sort_small_kernel, dim3(std::min<uint32_t>((nbk + 3) / 4, cu * 8)), dim3(256), 0, side, d_hits_raw_, d_perm_a_, d_fin_fill_, fin_done, lim, fin_cap,
+                             id_bits, to_bits, d_fin_kept_, d_fin_total_ + 1, d_fin_big_, d_fin_total_ + 2);
+          hipLaunchKernelGGL(hg_fin_sort_big_kernel, dim3(std::min<uint32_t>(nbk, cu * 3)), dim3(256), 0, side, d_hits_raw_, d_perm_a_, d_fin_fill_, d_fin_big_, d_fin_total_ + 2, fin_cap,
+                             id_bits, to_bits, d_fin_kept_, d_fin_total_ + 1, d_selected_ + 1);
+          hipLaunchKernelGGL(hg_fin_scan_kernel, dim3(1), dim3(1024), 0, side, d_fin_kept_, fin_done, lim, d_fin_total_);
+          hipLaunchKernelGGL(hg_fin_gather_kernel, dim3(std::min<uint32_t>((nbk + 3) / 4, cu * 8)), dim3(256), 0, side, d_hits_raw_, d_aux_raw_, d_perm_a_, d_fin_kept_, d_fin_total_,
+                             fin_done, lim, fin_cap, d_hits_out_, d_aux_out_);
+          HG_TRY(hipGetLastError(), "finalize launch");
+          fin_done = lim;
+        }
+      }
       if (piped) HG_TRY(hipEventRecord(ev_side_done_[c], side), "event");
     }
     if (piped) HG_TRY(hipStreamWaitEvent(stream, ev_side_done_[nchunks - 1], 0), "stream wait");
@@ -437,26 +489,12 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
     h_final_->L = line_base;
   }
   HG_TRY(hipMemcpyAsync(h_counters_, d_counters_, HG_CNT_WORDS * 4, hipMemcpyDeviceToHost, stream), "copy counters");
-  // Chunked pipeline: while the last chunk is still streaming, the hits of all earlier chunks are final.  They are keyed and
-  // sorted now, on a third stream; after the last chunk only its own hits are sorted and the two runs merged.  The key layout
-  // must be fixed before the line count is known: the line field is sized for one line per byte.
-  const uint32_t id_bits = bits_for(static_cast<uint64_t>(db_->max_id) + 1), to_bits = bits_for(bs1 + 1);
-  const uint32_t line_bits_bound = bits_for(line_base + nbytes + 1);
-  uint32_t n_early = 0;
-  if (piped && line_bits_bound + id_bits + to_bits + 1 <= 64) {
-    HG_TRY(hipEventSynchronize(ev_side_done_[nchunks - 2]), "event sync (early hits)");
-    const bool clean = !h_early_[HG_CNT_HIT_NEED] && !h_early_[HG_CNT_CAND_NEED] && !h_early_[HG_CNT_DEFER_NEED] && h_early_[HG_CNT_HITS] <= hit_cap_;
-    if (clean && h_early_[HG_CNT_HITS] >= 4096) {
-      n_early = h_early_[HG_CNT_HITS];
-      const HgPattern *pats = static_cast<const HgPattern *>(d_patterns_);
-      hipLaunchKernelGGL(hg_key_packed_kernel, dim3((n_early + 255) / 256), dim3(256), 0, fin_stream_, d_hits_raw_, d_aux_raw_, pats, n_early, id_bits, to_bits, d_key_a_, d_perm_a_);
-      size_t tb = temp_bytes_;
-      HG_TRY(rocprim::radix_sort_pairs(d_temp_, tb, d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, n_early, 0, line_bits_bound + id_bits + to_bits + 1, fin_stream_), "radix sort (early)");
-      HG_TRY(hipEventRecord(ev_fin_done_, fin_stream_), "event");
-    }
+  if (bucketed) {
+    HG_TRY(hipMemcpyAsync(h_counters_ + HG_CNT_WORDS, d_fin_total_, 8, hipMemcpyDeviceToHost, stream), "copy count");  // kept, raw
+    HG_TRY(hipMemcpyAsync(h_counters_ + HG_CNT_WORDS + 2, d_selected_ + 1, 4, hipMemcpyDeviceToHost, stream), "copy flag");
+    HG_TRY(hipEventRecord(ev_[3], stream), "event");
   }
   HG_TRY(hipStreamSynchronize(stream), "stream sync (scan kernels)");
-  if (n_early) HG_TRY(hipStreamWaitEvent(stream, ev_fin_done_, 0), "stream wait");
   if (piped) {
     for (uint32_t c = 0; c < nchunks; c++) {
       float ms = 0;
@@ -465,12 +503,13 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
     }
   }
 
-  const uint64_t n_cands = h_counters_[HG_CNT_CANDS], n_raw = h_counters_[HG_CNT_HITS];
+  const uint64_t n_cands = h_counters_[HG_CNT_CANDS];
+  const uint64_t n_raw = bucketed ? h_counters_[HG_CNT_WORDS + 1] : h_counters_[HG_CNT_HITS];
   const uint64_t cand_need = h_counters_[HG_CNT_CAND_NEED], hit_need = h_counters_[HG_CNT_HIT_NEED];
   const uint64_t defer_need = h_counters_[HG_CNT_DEFER_NEED];
-  if (cand_need || defer_need || hit_need || n_raw > hit_cap_) {
-    // a private segment (or the compact hit array) was too small: grow and let the caller repeat the pass
-    if (n_early) HG_TRY(hipStreamSynchronize(fin_stream_), "stream sync (early sort)");  // before its buffers are replaced
+  const bool fin_overflow = bucketed && h_counters_[HG_CNT_WORDS + 2] != 0;  // a bucket beyond what one block sorts
+  if (cand_need || defer_need || hit_need || fin_overflow || (!bucketed && n_raw > hit_cap_)) {
+    // a private segment, a bucket or the compact hit array was too small: grow and let the caller repeat the pass
     if (cand_need || defer_need) {
       uint64_t want = std::max<uint64_t>((cand_need + cand_need / 4 + 64) * wgs, (defer_need + defer_need / 4 + 64) * HG_DEFER_SHARDS);
       want = std::max<uint64_t>(want, static_cast<uint64_t>(cand_cap_) * 2);
@@ -481,7 +520,18 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       int rc = alloc_cands(want);
       if (rc) return rc;
     }
-    if (hit_need || n_raw > hit_cap_) {
+    if (bucketed && (hit_need || fin_overflow)) {
+      // hit_need = the fullest bucket's demand.  Equal bucket regions are fine while the hits are spread; when one bucket
+      // holds thousands of them (every match end of an all-matches expression on one long line) the scanner leaves bucketed
+      // emission for good: compact array + library sort.
+      const uint64_t want = (hit_need + hit_need / 4 + 16) * fin_nb;
+      if (fin_overflow || hit_need > HG_FIN_BUCKET_CAP || want > (64ull << 20)) {
+        fin_fallback_ = true;
+      } else {
+        int rc = alloc_hits(std::max<uint64_t>(want, static_cast<uint64_t>(hit_cap_) * 2));
+        if (rc) return rc;
+      }
+    } else if (hit_need || n_raw > hit_cap_) {
       uint64_t want = std::max<uint64_t>((hit_need + hit_need / 4 + 64) * std::max(confirm_blocks, always_blocks), n_raw + n_raw / 4);
       // equal segments sized for the fullest block: fine while the hits are spread, absurd when one block holds most of them
       // (every match end of an all-matches expression on one very long line).  Past 64 M records (4 GiB of workspace) or 16
@@ -507,7 +557,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   uint64_t n_pieces = block_mode ? 1 : h_final_->L - line_base + (nbytes > h_final_->cs ? hg_pieces(nbytes - h_final_->cs, bs1) : 0);
   uint32_t n = static_cast<uint32_t>(n_raw);
   uint32_t kept = 0;
-  if (n) {
+  if (n && !bucketed) {  // compact array + library sort (scanners that left bucketed emission, keys wider than 64 bits)
     const HgPattern *pats = static_cast<const HgPattern *>(d_patterns_);
     uint32_t blocks = (n + 255) / 256;
     // order by (line, id, to, single-after-multi): one radix sort over exactly the bits in use when they fit in 64, else two
@@ -515,23 +565,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
     const uint32_t *perm = nullptr;
     uint32_t *pos = nullptr;
     size_t tb = temp_bytes_;
-    if (n_early) {
-      // [0, n_early) is sorted in key_b / perm_b already: sort the last chunk's hits behind it and merge the two runs
-      const uint32_t n_late = n - n_early;
-      if (n_late) {
-        hipLaunchKernelGGL(hg_key_packed_kernel, dim3((n_late + 255) / 256), dim3(256), 0, stream, d_hits_raw_ + n_early, d_aux_raw_ + n_early, pats, n_late, id_bits, to_bits,
-                           d_key_a_ + n_early, d_perm_a_ + n_early);
-        hipLaunchKernelGGL(hg_offset_kernel, dim3((n_late + 255) / 256), dim3(256), 0, stream, d_perm_a_ + n_early, n_late, n_early);
-        // same key layout as the early run, but by now the line count is known: the bits above it are zero in every key
-        HG_TRY(rocprim::radix_sort_pairs(d_temp_, tb, d_key_a_ + n_early, d_key_b_ + n_early, d_perm_a_ + n_early, d_perm_b_ + n_early, n_late, 0,
-                                         std::min(line_bits, line_bits_bound) + id_bits + to_bits + 1, stream), "radix sort (last chunk)");
-      }
-      tb = temp_bytes_;
-      // (keys 1, keys 2, keys out, values 1, values 2, values out)
-      HG_TRY(rocprim::merge(d_temp_, tb, d_key_b_, d_key_b_ + n_early, d_key_a_, d_perm_b_, d_perm_b_ + n_early, d_perm_a_, n_early, n_late, rocprim::less<uint64_t>(), stream), "merge");
-      perm = d_perm_a_;
-      pos = d_perm_b_;
-    } else if (line_bits + id_bits + to_bits + 1 <= 64) {
+    if (line_bits + id_bits + to_bits + 1 <= 64) {
       hipLaunchKernelGGL(hg_key_packed_kernel, dim3(blocks), dim3(256), 0, stream, d_hits_raw_, d_aux_raw_, pats, n, id_bits, to_bits, d_key_a_, d_perm_a_);
       HG_TRY(rocprim::radix_sort_pairs(d_temp_, tb, d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, n, 0, line_bits + id_bits + to_bits + 1, stream), "radix sort");
       perm = d_perm_b_;
@@ -552,8 +586,10 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
     HG_TRY(hipGetLastError(), "finalize launch");
     HG_TRY(hipMemcpyAsync(h_counters_ + HG_CNT_WORDS, d_selected_, 4, hipMemcpyDeviceToHost, stream), "copy count");
   }
-  HG_TRY(hipEventRecord(ev_[3], stream), "event");
-  HG_TRY(hipStreamSynchronize(stream), "stream sync (finalize)");
+  if (!bucketed) {
+    HG_TRY(hipEventRecord(ev_[3], stream), "event");
+    HG_TRY(hipStreamSynchronize(stream), "stream sync (finalize)");
+  }
   if (n) kept = h_counters_[HG_CNT_WORDS];
   out->n_hits = kept;
   out->n_pieces = n_pieces;

@@ -774,7 +774,20 @@ struct HitSink {
   // The engine turns it on when equal segments for every block would have to grow past any sensible size because ONE block
   // holds most of the hits (all match ends of an all-matches expression on a very long line).  (The compact array's
   // fields are read from the kernel arguments at the call, not kept here: a larger struct went through scratch.)
-  __device__ __forceinline__ void push(const HgConfirmArgs &a, uint64_t line_no, uint32_t id, uint32_t to, uint64_t start, uint32_t len, uint32_t pattern) const {
+  __device__ __forceinline__ void push(const HgConfirmArgs &a, uint64_t line_no, uint32_t id, uint32_t to, uint64_t start, uint32_t len, uint32_t pattern,
+                                       bool single) const {
+    if (a.bucket_cap) {  // straight into the bucket of the line's start; the finalize kernels order each bucket
+      const uint32_t b = static_cast<uint32_t>(start >> a.bucket_shift);
+      const uint32_t slot = atomicAdd(&a.bucket_fill[b], 1u);
+      if (slot < a.bucket_cap) {
+        const uint64_t at = static_cast<uint64_t>(b) * a.bucket_cap + slot;
+        a.hits[at] = HgHit{line_no, id, to | (single ? HG_HIT_SINGLE_BIT : 0u)};
+        a.aux[at] = HgHitAux{start, len, pattern};
+      } else {
+        atomicMax(&a.counters[HG_CNT_HIT_NEED], slot + 1u);  // the engine grows the buckets (or leaves bucketed emission) and repeats the pass
+      }
+      return;
+    }
     const uint32_t slot = atomicAdd(lds_count, 1u);
     if (slot < seg_cap) {
       seg_hits[slot] = HgHit{line_no, id, to};
@@ -790,6 +803,7 @@ struct HitSink {
 };
 
 __device__ __forceinline__ void flush_hits(const HgConfirmArgs &a, uint32_t *lds_count, uint32_t *lds_base) {
+  if (a.bucket_cap) return;  // (block-uniform) nothing was staged
   __syncthreads();
   if (threadIdx.x == 0) {
     const uint32_t n = *lds_count;
@@ -1024,7 +1038,8 @@ __device__ __forceinline__ void confirm_body(const HgConfirmArgs &a, uint32_t vb
     const uint32_t pattern = d.pattern & (HG_MAX_PATTERNS - 1u);
     const HgPattern &p = a.db.patterns[pattern];
     const uint32_t id = p.id;
-    auto emit = [&](uint64_t line_no, uint32_t to, uint64_t start, uint32_t len) { sink.push(a, line_no, id, to, start, len, pattern); };
+    const bool single = MODE != 3 || p.single != 0;  // modes 0..2 are SINGLEMATCH expressions by definition (hg_confirm_mode)
+    auto emit = [&](uint64_t line_no, uint32_t to, uint64_t start, uint32_t len) { sink.push(a, line_no, id, to, start, len, pattern, single); };
     if (MODE == 0) hgdev::confirm_literal(a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, d.rank, d.pos - (d.pattern >> 24), p.max_len, emit);
     else hg_confirm(a.db, a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, pattern, d.rank, emit);
   }
@@ -1057,10 +1072,33 @@ __device__ __forceinline__ void stage_tables(hgdev::lds_u32 *tab, const uint32_t
   }
 }
 
+// Single-word automata (<= 32 nodes), the common case of the always-on tier, with the follow step table-driven: fu[t][b] is
+// the union of follow[] over the set bits of byte t of the state word, so a step is <= 4 independent LDS reads instead of a
+// loop over the set bits, and the per-byte work is straight-line selects (newline / NUL / segment edges) with three rarely
+// taken branches (forced break, match to note, match ending with the line).  Same results as always_on_segment<1, *>.
+constexpr uint32_t CT_FU = CT_WORDS;              // fu[4][256]
+constexpr uint32_t AO_TAB_WORDS = CT_WORDS + 1024;  // a wave's table area in hg_always_on_fast_kernel
+__device__ __forceinline__ void stage_follow_unions(hgdev::lds_u32 *tab, uint32_t nnodes, uint32_t lane) {
+  // sixteen lanes per table; a lane fixes the low nibble of the index and walks the high one
+  const uint32_t t = lane >> 4, j = lane & 15u;
+  uint32_t f[8];
+#pragma unroll
+  for (uint32_t b = 0; b < 8; b++) f[b] = 8 * t + b < nnodes ? tab[CT_FOLLOW + 8 * t + b] : 0u;
+  uint32_t low = 0;
+#pragma unroll
+  for (uint32_t b = 0; b < 4; b++) low |= ((j >> b) & 1u) ? f[b] : 0u;
+#pragma unroll
+  for (uint32_t m = 0; m < 16; m++) {
+    uint32_t e = low;
+#pragma unroll
+    for (uint32_t b = 0; b < 4; b++) e |= ((m >> b) & 1u) ? f[4 + b] : 0u;
+    tab[CT_FU + t * 256 + m * 16 + j] = e;
+  }
+}
+
 template <int MODE>
-__device__ __forceinline__ void confirm_tables_body(const HgConfirmArgs &a, uint32_t vblock, uint32_t vgrid) {
+__device__ __forceinline__ void confirm_tables_body(const HgConfirmArgs &a, uint32_t vblock, uint32_t vgrid, uint32_t *s_tab) {
   __shared__ uint32_t s_n, s_base;
-  __shared__ __attribute__((aligned(16))) uint32_t s_tab[(HG_CONFIRM_THREADS / 64) * CT_WORDS];
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
   const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
@@ -1101,7 +1139,7 @@ __device__ __forceinline__ void confirm_tables_body(const HgConfirmArgs &a, uint
       __builtin_amdgcn_wave_barrier();
       if (mine) {
         const uint32_t id = p.id;
-        auto emit = [&](uint64_t line_no, uint32_t to, uint64_t start_, uint32_t len) { sink.push(a, line_no, id, to, start_, len, pat); };
+        auto emit = [&](uint64_t line_no, uint32_t to, uint64_t start_, uint32_t len) { sink.push(a, line_no, id, to, start_, len, pat, true); };
         if (MODE == 1) {
           hgdev::confirm_simple(a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, d.rank, p.init_word, p.acc_all, tab + CT_REACH, tab + CT_FOLLOW, emit);
         } else if (nw == 1) {
@@ -1126,9 +1164,10 @@ __global__ __launch_bounds__(HG_CONFIRM_THREADS) void hg_confirm_fast_kernel(HgC
   uint32_t mode = 0, seen = 0;
   for (uint32_t m = 0; m < 3; m++)
     if (a.mode_present[m] && seen++ == k) mode = m;
+  __shared__ __attribute__((aligned(16))) uint32_t s_tab[(HG_CONFIRM_THREADS / 64) * CT_WORDS];  // a table area per wave (modes 1, 2)
   if (mode == 0) confirm_body<0>(a, vblock, blocks_per_mode);
-  else if (mode == 1) confirm_tables_body<1>(a, vblock, blocks_per_mode);
-  else confirm_tables_body<2>(a, vblock, blocks_per_mode);
+  else if (mode == 1) confirm_tables_body<1>(a, vblock, blocks_per_mode, s_tab);
+  else confirm_tables_body<2>(a, vblock, blocks_per_mode, s_tab);
 }
 __global__ __launch_bounds__(256) void hg_confirm_generic_kernel(HgConfirmArgs a) { confirm_body<3>(a, blockIdx.x, gridDim.x); }
 
@@ -1153,7 +1192,7 @@ __global__ __launch_bounds__(256) void hg_always_on_kernel(HgConfirmArgs a, uint
       if (starts)
         hg_scan_line_always_on(a.db, a.text, a.nbytes, a.sums, a.bases, a.bs1, s, rank, first, last,
                                [&](uint32_t pi, uint64_t line_no, uint32_t to, uint64_t start, uint32_t len) {
-                                 sink.push(a, line_no, a.db.patterns[pi].id, to, start, len, pi);
+                                 sink.push(a, line_no, a.db.patterns[pi].id, to, start, len, pi, a.db.patterns[pi].single != 0);
                                });
       rank += a.text[s] == '\n';
     }
@@ -1322,30 +1361,6 @@ __device__ __forceinline__ void always_on_segment(const AlwaysOnCtx &a, const Hg
         pc = hg_prev_ctx(c);
       }
     }
-  }
-}
-
-// Single-word automata (<= 32 nodes), the common case of the always-on tier, with the follow step table-driven: fu[t][b] is
-// the union of follow[] over the set bits of byte t of the state word, so a step is <= 4 independent LDS reads instead of a
-// loop over the set bits, and the per-byte work is straight-line selects (newline / NUL / segment edges) with three rarely
-// taken branches (forced break, match to note, match ending with the line).  Same results as always_on_segment<1, *>.
-constexpr uint32_t CT_FU = CT_WORDS;              // fu[4][256]
-constexpr uint32_t AO_TAB_WORDS = CT_WORDS + 1024;  // a wave's table area in hg_always_on_fast_kernel
-__device__ __forceinline__ void stage_follow_unions(hgdev::lds_u32 *tab, uint32_t nnodes, uint32_t lane) {
-  // sixteen lanes per table; a lane fixes the low nibble of the index and walks the high one
-  const uint32_t t = lane >> 4, j = lane & 15u;
-  uint32_t f[8];
-#pragma unroll
-  for (uint32_t b = 0; b < 8; b++) f[b] = 8 * t + b < nnodes ? tab[CT_FOLLOW + 8 * t + b] : 0u;
-  uint32_t low = 0;
-#pragma unroll
-  for (uint32_t b = 0; b < 4; b++) low |= ((j >> b) & 1u) ? f[b] : 0u;
-#pragma unroll
-  for (uint32_t m = 0; m < 16; m++) {
-    uint32_t e = low;
-#pragma unroll
-    for (uint32_t b = 0; b < 4; b++) e |= ((m >> b) & 1u) ? f[4 + b] : 0u;
-    tab[CT_FU + t * 256 + m * 16 + j] = e;
   }
 }
 
@@ -1629,7 +1644,8 @@ __global__ __launch_bounds__(256) void hg_always_on_finish_kernel(HgConfirmArgs 
       if (blocked) continue;
     }
     const uint64_t z = a.text[pos] == '\n' ? end : hgdev::scanned_end(a.text, end, pv.limit);
-    sink.push(a, pv.line_no, a.db.patterns[d.pattern].id, static_cast<uint32_t>(end - pv.a), pv.a, static_cast<uint32_t>(z - pv.a), d.pattern);
+    const HgPattern &pat = a.db.patterns[d.pattern];
+    sink.push(a, pv.line_no, pat.id, static_cast<uint32_t>(end - pv.a), pv.a, static_cast<uint32_t>(z - pv.a), d.pattern, pat.single != 0);
   }
   flush_hits(a, &s_n, &s_base);
 }
@@ -1657,9 +1673,205 @@ __global__ __launch_bounds__(256) void hg_block_scan_kernel(HgConfirmArgs a, con
     const HgPattern &pat = a.db.patterns[p];
     if (pat.tier == 0 && !pattern_flags[p]) continue;
     hg_nfa_scan(a.db.pool, pat, a.text, a.nbytes,
-                [&](uint32_t to) { sink.push(a, 0, pat.id, to, 0, static_cast<uint32_t>(a.nbytes), p); });
+                [&](uint32_t to) { sink.push(a, 0, pat.id, to, 0, static_cast<uint32_t>(a.nbytes), p, pat.single != 0); });
   }
   flush_hits(a, &s_n, &s_base);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Finalize, bucketed (the default): order by (line, id, to), SINGLEMATCH / duplicate rules, compaction.
+// The confirm passes put every hit straight into the bucket of its line's start (HitSink::push): a line's start position
+// grows with its number, so the buckets are in final order among themselves and all reports of one line sit in ONE bucket,
+// whichever pipeline chunk found them.  Per range of buckets (a chunk of the pipeline, as soon as its side passes are
+// done): sort each bucket (a few dozen records: one wave, bitonic network over the lanes, no LDS; larger ones in LDS),
+// apply the report rules on the sorted keys, scan the kept counts, gather the kept records to their final places.  Only
+// the last chunk's buckets are finalized after the last scan kernel; no library sort, no host round trip in between.
+// A bucket larger than HG_FIN_BUCKET_CAP (thousands of reports in one bucket: every match end of an all-matches expression
+// on a long line) raises a flag and the engine repeats the pass with the compact array + library sort (hg_key/keep/scatter).
+__device__ __forceinline__ uint64_t fin_key(const HgHit &h, uint32_t id_bits, uint32_t to_bits) {
+  HgHit c = h;
+  c.to &= ~HG_HIT_SINGLE_BIT;
+  return hg_sort_key_packed(c, (h.to & HG_HIT_SINGLE_BIT) != 0, id_bits, to_bits);
+}
+// Report rules on sorted packed keys (hg_keep_hit_at restated): equal (line, id, to) <=> keys equal above bit 0; a
+// SINGLEMATCH report (bit 0) is kept only if it is the first one of its (line, id) = key >> group_shift.
+// Buckets of up to 64 reports (nearly all of them): one wave, one report per lane, the rules as bit operations on ballots.
+__global__ __launch_bounds__(256) void hg_fin_sort_small_kernel(const HgHit *hits, uint32_t *idx, const uint32_t *fill, uint32_t b_lo, uint32_t b_hi, uint32_t cap,
+                                                                uint32_t id_bits, uint32_t to_bits, uint32_t *kept_count, uint32_t *raw_total, uint32_t *big_list,
+                                                                uint32_t *big_count) {
+  const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t group_shift = to_bits + 1;
+  uint32_t seen = 0;
+  for (uint32_t b = b_lo + wave; b < b_hi; b += waves) {
+    uint32_t n = fill[b];
+    if (n > cap) n = cap;  // (overflowed: the pass is repeated anyway)
+    if (n > 64) {  // hg_fin_sort_big_kernel's: noted in its work list
+      if (lane == 0) big_list[atomicAdd(big_count, 1u)] = b;
+      continue;
+    }
+    if (n == 0) {
+      if (lane == 0) kept_count[b] = 0;
+      continue;
+    }
+    seen += n;
+    const uint32_t b0 = b * cap;
+    uint64_t k = lane < n ? fin_key(hits[b0 + lane], id_bits, to_bits) : ~0ull;  // (padding sorts last; a real key never has all bits set)
+    uint32_t x = b0 + lane;
+    if (n > 1) {
+#pragma unroll
+      for (uint32_t kk = 2; kk <= 64; kk <<= 1) {
+#pragma unroll
+        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+          const uint32_t lo32 = __shfl_xor(static_cast<uint32_t>(k), j, 64), hi32 = __shfl_xor(static_cast<uint32_t>(k >> 32), j, 64);
+          const uint64_t other = (static_cast<uint64_t>(hi32) << 32) | lo32;
+          const uint32_t ox = __shfl_xor(x, j, 64);
+          const bool lower = (lane & j) == 0, up = (lane & kk) == 0;
+          const bool take = (lower == up) ? (other < k) : (other > k);  // ascending run: the lower lane keeps the smaller key
+          if (take) {
+            k = other;
+            x = ox;
+          }
+        }
+      }
+    }
+    const uint32_t plo = __shfl_up(static_cast<uint32_t>(k), 1, 64), phi = __shfl_up(static_cast<uint32_t>(k >> 32), 1, 64);
+    const uint64_t prev = (static_cast<uint64_t>(phi) << 32) | plo;
+    const bool valid = lane < n;
+    const bool dup = valid && lane > 0 && (prev >> 1) == (k >> 1);
+    const bool head = valid && (lane == 0 || (prev >> group_shift) != (k >> group_shift));
+    const uint64_t head_mask = __builtin_amdgcn_ballot_w64(head), single_mask = __builtin_amdgcn_ballot_w64(valid && (k & 1u));
+    const uint64_t upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull), below = (1ull << lane) - 1ull;
+    const uint32_t group_start = 63u - static_cast<uint32_t>(__builtin_clzll((head_mask & upto) | 1ull));
+    const bool earlier_single = (single_mask & below & ~((1ull << group_start) - 1ull)) != 0;
+    const bool keep = valid && !dup && !((k & 1u) && earlier_single);
+    const uint64_t km = __builtin_amdgcn_ballot_w64(keep);
+    if (keep) idx[b0 + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(km >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(km), 0u))] = x;
+    if (lane == 0) kept_count[b] = static_cast<uint32_t>(__popcll(km));
+  }
+  if (lane == 0 && seen) atomicAdd(raw_total, seen);
+}
+// Larger buckets (hits clustered on few lines): one block sorts the bucket in LDS.
+__global__ __launch_bounds__(256) void hg_fin_sort_big_kernel(const HgHit *hits, uint32_t *idx, const uint32_t *fill, const uint32_t *big_list, const uint32_t *big_count,
+                                                              uint32_t cap, uint32_t id_bits, uint32_t to_bits, uint32_t *kept_count, uint32_t *raw_total, uint32_t *overflow) {
+  __shared__ uint64_t s_key[HG_FIN_BUCKET_CAP];
+  __shared__ uint32_t s_idx[HG_FIN_BUCKET_CAP];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t group_shift = to_bits + 1;  // key >> group_shift == (line, id)
+  const uint32_t nbig = *big_count;
+  for (uint32_t q = blockIdx.x; q < nbig; q += gridDim.x) {
+    const uint32_t b = big_list[q];
+    uint32_t n = fill[b];
+    if (n > cap) n = cap;
+    if (n > HG_FIN_BUCKET_CAP) {
+      if (tid == 0) {
+        kept_count[b] = 0;
+        atomicMax(overflow, n);
+      }
+      continue;
+    }
+    const uint32_t b0 = b * cap;
+    uint32_t p2 = 128;
+    while (p2 < n) p2 <<= 1;
+    for (uint32_t i = tid; i < p2; i += 256) {
+      s_key[i] = i < n ? fin_key(hits[b0 + i], id_bits, to_bits) : ~0ull;
+      s_idx[i] = b0 + i;
+    }
+    if (tid == 0) atomicAdd(raw_total, n);
+    __syncthreads();
+    for (uint32_t k = 2; k <= p2; k <<= 1)
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        for (uint32_t t = tid; t < (p2 >> 1); t += 256) {
+          const uint32_t lo = 2 * t - (t & (j - 1)), hi = lo + j;  // partner pairs at distance j
+          const bool up = (lo & k) == 0;
+          const uint64_t a = s_key[lo], c = s_key[hi];
+          if ((a > c) == up) {
+            s_key[lo] = c;
+            s_key[hi] = a;
+            const uint32_t x = s_idx[lo];
+            s_idx[lo] = s_idx[hi];
+            s_idx[hi] = x;
+          }
+        }
+        __syncthreads();
+      }
+    // rules + compaction, 64 sorted records at a time by the first wave (the other waves wait: a large bucket is rare)
+    if (tid < 64) {
+      uint32_t kept = 0;
+      for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+        const uint32_t i = i0 + lane;
+        bool keep = false;
+        if (i < n) {
+          const uint64_t k = s_key[i];
+          keep = !(i > 0 && (s_key[i - 1] >> 1) == (k >> 1));  // the same report is already there (either kind)
+          if (keep && (k & 1u)) {  // only the first SINGLEMATCH report of this (line, id)
+            for (uint32_t j = i; j > 0; j--) {
+              const uint64_t q = s_key[j - 1];
+              if ((q >> group_shift) != (k >> group_shift)) break;
+              if (q & 1u) {
+                keep = false;
+                break;
+              }
+            }
+          }
+        }
+        const uint64_t km = __builtin_amdgcn_ballot_w64(keep);
+        if (keep) idx[b0 + kept + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(km >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(km), 0u))] = s_idx[i];
+        kept += static_cast<uint32_t>(__popcll(km));
+      }
+      if (lane == 0) kept_count[b] = kept;
+    }
+    __syncthreads();
+  }
+}
+// One block: kept_count[b_lo, b_hi) -> exclusive positions in the compact output, continuing from *total (the kept records of
+// the bucket ranges finalized before); *total moves on.
+constexpr uint32_t HG_FIN_SCAN_THREADS = 1024;
+__global__ __launch_bounds__(HG_FIN_SCAN_THREADS) void hg_fin_scan_kernel(uint32_t *kept_count, uint32_t b_lo, uint32_t b_hi, uint32_t *total) {
+  __shared__ uint32_t s_wave[HG_FIN_SCAN_THREADS / 64];
+  constexpr uint32_t WAVES = HG_FIN_SCAN_THREADS / 64;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t carry = *total;
+  // wave w owns a contiguous share of the range and walks it 64 entries at a time (coalesced): first the share's sum ...
+  const uint32_t share = ((b_hi - b_lo + WAVES - 1) / WAVES + 63u) & ~63u;
+  const uint32_t w_lo = b_lo + wave * share, w_hi = w_lo + share < b_hi ? w_lo + share : b_hi;
+  uint32_t sum = 0;
+#pragma unroll 8
+  for (uint32_t i = w_lo + lane; i < w_hi; i += 64) sum += kept_count[i];
+  sum = wave_inclusive_scan(sum, lane);
+  if (lane == 63) s_wave[wave] = sum;
+  __syncthreads();  // (also: everyone has read *total before thread 0 rewrites it)
+  uint32_t run = carry, all = 0;
+#pragma unroll
+  for (uint32_t w = 0; w < WAVES; w++) {
+    const uint32_t t = s_wave[w];
+    run += w < wave ? t : 0u;
+    all += t;
+  }
+  // ... then the exclusive positions (the entries come from the cache this time)
+  for (uint32_t i0 = w_lo; i0 < w_hi; i0 += 64) {
+    const uint32_t i = i0 + lane;
+    const uint32_t c = i < w_hi ? kept_count[i] : 0u;
+    const uint32_t incl = wave_inclusive_scan(c, lane);
+    if (i < w_hi) kept_count[i] = run + incl - c;
+    run += __builtin_amdgcn_readlane(incl, 63);
+  }
+  if (threadIdx.x == 0) *total = carry + all;
+}
+// kept records of bucket b (idx[b * cap ...] in final order) -> out[kept_base[b] ...]; bucket b + 1's base (or *total for the
+// last bucket of the range) ends the run.  One wave per bucket, grid-stride.
+__global__ void hg_fin_gather_kernel(const HgHit *hits, const HgHitAux *aux, const uint32_t *idx, const uint32_t *kept_base, const uint32_t *total, uint32_t b_lo,
+                                     uint32_t b_hi, uint32_t cap, HgHit *oh, HgHitAux *oa) {
+  const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t b = b_lo + wave; b < b_hi; b += waves) {
+    const uint32_t k0 = kept_base[b], k1 = b + 1 < b_hi ? kept_base[b + 1] : *total, b0 = b * cap;
+    for (uint32_t i = lane; i < k1 - k0; i += 64) {
+      const uint32_t src = idx[b0 + i];
+      HgHit h = hits[src];
+      h.to &= ~HG_HIT_SINGLE_BIT;
+      oh[k0 + i] = h;
+      oa[k0 + i] = aux[src];
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
