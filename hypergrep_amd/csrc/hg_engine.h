@@ -10,6 +10,12 @@
 #include "hg_core.h"
 #include "hg_post.h"
 
+// Waves per stream workgroup (one 16 KiB tile per wave at a time); shared by the kernel and the grid sizing.
+#ifndef HG_STREAM_WG_WAVES
+#define HG_STREAM_WG_WAVES 8
+#endif
+constexpr uint32_t HG_STREAM_WG_WAVES_DEFAULT = HG_STREAM_WG_WAVES;
+
 // device counters: totals, and the largest per-segment demand seen when a private segment overflowed
 constexpr uint32_t HG_CONFIRM_SPLIT = 4;   // verify blocks per candidate segment
 constexpr uint32_t HG_DEFER_SHARDS = 64;   // append-only lists of verified candidates that need an automaton run
@@ -20,7 +26,10 @@ struct HgDeferred {
   uint32_t pattern;   // pattern index | offset of the window inside the literal << 24
   uint32_t rank;      // newlines between the tile start and pos
 };
-enum { HG_CNT_CANDS = 0, HG_CNT_HITS = 1, HG_CNT_CAND_NEED = 2, HG_CNT_HIT_NEED = 3, HG_CNT_DEFER_NEED = 4, HG_CNT_WORDS = 8 };
+enum { HG_CNT_CANDS = 0, HG_CNT_HITS = 1, HG_CNT_CAND_NEED = 2, HG_CNT_HIT_NEED = 3, HG_CNT_DEFER_NEED = 4, HG_CNT_WORDS = 8,
+       HG_CNT_CURSOR0 = 8,      // one tile cursor per pipeline chunk follows the counters proper
+       HG_CNT_ALL_WORDS = 8 + 16 };
+constexpr uint32_t HG_STREAM_GRAB = 2 * HG_STREAM_WG_WAVES_DEFAULT;  // tiles per draw of a stream workgroup: two per wave
 
 // Bucketed finalize (hg_fin_*): buckets of the final ordering and the largest bucket one wave sorts in LDS.
 constexpr uint32_t HG_FIN_MAX_BUCKETS = 1u << 16;
@@ -32,10 +41,7 @@ constexpr uint32_t HG_FIN_BUCKET_CAP = 4096;
 #define HG_CONFIRM_THREADS 128
 #endif
 
-// Waves per stream workgroup (one 16 KiB tile per wave at a time); shared by the kernel and the grid sizing.
-#ifndef HG_STREAM_WG_WAVES
-#define HG_STREAM_WG_WAVES 8
-#endif
+
 
 struct HgStreamArgs {
   const uint8_t *text;
@@ -52,7 +58,7 @@ struct HgStreamArgs {
   uint32_t dense;  // byte-aligned probing (HgDb::dense)
   uint32_t weights_c;  // hash C weights (HgDb::weights_c)
   uint32_t alone;  // no other kernel runs next to this launch (every workgroup slot is its own)
-  uint32_t span;  // tiles per workgroup when each owns a consecutive range, 0 = round-robin (hg_stream_kernel)
+  uint32_t cursor_slot;  // counters[cursor_slot] = tiles of the chunk handed out so far (hg_stream_kernel draws runs of HG_STREAM_GRAB tiles)
   uint32_t *counters;
 };
 

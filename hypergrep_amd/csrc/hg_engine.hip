@@ -122,7 +122,7 @@ int HgScanner::create(std::shared_ptr<const HgDb> db, int device, HgScanner **ou
   s->view_.nslow_fast = db->nslow_fast;
   s->view_.fold_mask = db->fold_mask;
   s->view_.window_mask = db->window_mask;
-  HG_TRY(hgmem::dev_alloc(&s->d_counters_, HG_CNT_WORDS * 4, "d_counters_"), "alloc counters");
+  HG_TRY(hgmem::dev_alloc(&s->d_counters_, HG_CNT_ALL_WORDS * 4, "d_counters_"), "alloc counters");
   HG_TRY(hgmem::dev_alloc(&s->d_selected_, 16, "d_selected_"), "alloc counters");
   HG_TRY(hgmem::dev_alloc(&s->d_final_, sizeof(HgTileBase), "d_final_"), "alloc state");
   HG_TRY(hgmem::dev_alloc(&s->d_pflags_, db->patterns.size() * 4 + 16, "d_pflags_"), "alloc pattern flags");
@@ -130,6 +130,7 @@ int HgScanner::create(std::shared_ptr<const HgDb> db, int device, HgScanner **ou
   HG_TRY(hgmem::host_alloc(&s->h_final_, sizeof(HgTileBase), "h_final_"), "alloc pinned");
   for (auto &ev : s->ev_) HG_TRY(hipEventCreate(&ev), "hipEventCreate");
   HG_TRY(hipStreamCreateWithFlags(&s->side_stream_, hipStreamNonBlocking), "hipStreamCreate");
+
   HG_TRY(hgmem::dev_alloc(&s->d_fin_fill_, HG_FIN_MAX_BUCKETS * 4, "d_fin_fill_"), "alloc finalize buckets");
   HG_TRY(hgmem::dev_alloc(&s->d_fin_kept_, HG_FIN_MAX_BUCKETS * 4, "d_fin_kept_"), "alloc finalize buckets");
   HG_TRY(hgmem::dev_alloc(&s->d_fin_total_, 16, "d_fin_total_"), "alloc finalize buckets");
@@ -157,6 +158,7 @@ HgScanner::~HgScanner() {
     if (ev_side_done_[i]) (void)hipEventDestroy(ev_side_done_[i]);
   }
   if (side_stream_) (void)hipStreamDestroy(side_stream_);
+
   hgmem::dev_free(d_fin_fill_, "d_fin_fill_");
   hgmem::dev_free(d_fin_kept_, "d_fin_kept_");
   hgmem::dev_free(d_fin_total_, "d_fin_total_");
@@ -236,7 +238,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   const uint64_t ntiles = (nbytes + HG_TILE_BYTES - 1) / HG_TILE_BYTES;
 #define HG_TRY(call, what) \
   if (fail((call), what)) return HG_ERR_HIP;
-  HG_TRY(hipMemsetAsync(d_counters_, 0, HG_CNT_WORDS * 4, stream), "memset counters");
+  HG_TRY(hipMemsetAsync(d_counters_, 0, HG_CNT_ALL_WORDS * 4, stream), "memset counters");
   HG_TRY(hipEventRecord(ev_[0], stream), "event");
   // Bucketed emission + finalize (hg_fin_*): buckets of 2^fin_shift text bytes (4 KiB at least) by line start, at most
   // HG_FIN_MAX_BUCKETS of them, each a region of fin_cap records of the hit arrays.  The packed sort key must hold the line
@@ -356,17 +358,14 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       sa.filter_wide = db_->filter_wide;
       sa.dense = db_->dense;
       sa.weights_c = db_->weights_c;
-      // every workgroup streams its own consecutive range of tiles: same HBM rate as dealing tiles round-robin (measured),
-      // and the verify / confirm passes then find neighbouring lines in neighbouring lanes (confirm 1.8 -> 1.5 ms per 32 GiB)
-      sa.span = static_cast<uint32_t>(((t1 - t0 + wgs_c - 1) / wgs_c + STREAM_WG_WAVES - 1) / STREAM_WG_WAVES * STREAM_WG_WAVES);
-      if (const char *env = std::getenv("HG_STREAM_ROUND_ROBIN")) {
-        if (std::atoi(env)) sa.span = 0;
-      }
+      // the chunk's workgroups draw runs of consecutive tiles from a cursor (hg_stream_kernel): two tiles per wave and draw
+      sa.cursor_slot = HG_CNT_CURSOR0 + c;
       sa.ext = static_cast<const HgSlotInfo *>(d_ext_);
       sa.sums = d_sums_;
       sa.cands = cands;
       sa.seg_count = seg_count;
-      sa.cand_seg_cap = cand_cap_ / wgs_c;
+      const uint32_t segs_c = wgs_c;  // candidate segments of the chunk: one per stream workgroup
+      sa.cand_seg_cap = cand_cap_ / segs_c;
       sa.alone = (c == 0 && wgs_c == wgs_alone && !std::getenv("HG_STREAM_WGS_PER_CU")) ? 1u : 0u;
       sa.counters = d_counters_;
       HG_TRY(hipEventRecord(piped ? ev_k1_begin_[c] : ev_[1], stream), "event");
@@ -399,7 +398,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       ca.counters = d_counters_;
       if (block_mode) {
         HG_TRY(hipMemsetAsync(d_pflags_, 0, db_->patterns.size() * 4, side), "memset pattern flags");
-        if (has_anchored) hipLaunchKernelGGL(hg_block_mark_kernel, dim3(wgs_c), dim3(256), 0, side, ca, d_pflags_);
+        if (has_anchored) hipLaunchKernelGGL(hg_block_mark_kernel, dim3(segs_c), dim3(256), 0, side, ca, d_pflags_);
         always_blocks = static_cast<uint32_t>((db_->patterns.size() + 255) / 256);
         ca.hit_seg_cap = hit_cap_ / always_blocks;
         hipLaunchKernelGGL(hg_block_scan_kernel, dim3(always_blocks), dim3(256), 0, side, ca, d_pflags_);
@@ -416,7 +415,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
         hipLaunchKernelGGL(hg_tile_apply_kernel, dim3(nblocks), dim3(256), 0, side, d_sums_, t0, t1, bs1, d_block_base_, d_bases_);
         HG_TRY(hipGetLastError(), "tile scan launch");
         if (has_anchored) {
-          const uint32_t verify_blocks = wgs_c * HG_CONFIRM_SPLIT;  // HG_CONFIRM_SPLIT blocks share candidate segment b
+          const uint32_t verify_blocks = segs_c * HG_CONFIRM_SPLIT;  // HG_CONFIRM_SPLIT blocks share candidate segment b
           uint32_t fast_modes = 0, mode_mask = 0xF;
           if (const char *env = std::getenv("HG_DEBUG_CONFIRM_MODES")) mode_mask = static_cast<uint32_t>(std::strtoul(env, nullptr, 0));  // profiling aid: results are incomplete
           for (uint32_t m = 0; m < 3; m++) fast_modes += (db_->n_confirm_mode[m] && ((mode_mask >> m) & 1u)) ? 1 : 0;
