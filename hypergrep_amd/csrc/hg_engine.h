@@ -26,6 +26,10 @@ struct HgDeferred {
   uint32_t pattern;   // pattern index | offset of the window inside the literal << 24
   uint32_t rank;      // newlines between the tile start and pos
 };
+// The scanner's small device state is ONE block of words (reset by one launch, read back by one copy):
+//   [0, 8) counters, [8, 24) tile cursors, [24, 28) finalize totals {kept, raw, large buckets, -}, [28, 30) {count, overflow flag}
+//   of the finalize, [32, 36) tile-scan state (HgTileBase)
+enum { HG_ST_FIN_TOTAL = 24, HG_ST_SELECTED = 28, HG_ST_FINAL = 32, HG_ST_WORDS = 36, HG_ST_ZERO_WORDS = 32 };
 enum { HG_CNT_CANDS = 0, HG_CNT_HITS = 1, HG_CNT_CAND_NEED = 2, HG_CNT_HIT_NEED = 3, HG_CNT_DEFER_NEED = 4, HG_CNT_WORDS = 8,
        HG_CNT_CURSOR0 = 8,      // one tile cursor per pipeline chunk follows the counters proper
        HG_CNT_ALL_WORDS = 8 + 16 };

@@ -28,6 +28,8 @@ __global__ void hg_always_on_fast_kernel(HgConfirmArgs a);
 __global__ void hg_always_on_finish_kernel(HgConfirmArgs a);
 __global__ void hg_block_mark_kernel(HgConfirmArgs a, uint32_t *pattern_flags);
 __global__ void hg_block_scan_kernel(HgConfirmArgs a, const uint32_t *pattern_flags);
+__global__ void hg_reset_kernel(uint32_t *state, uint32_t state_words, HgTileBase *final_state, uint64_t line_base, uint32_t *fill, uint32_t nb, uint32_t *defer_count,
+                                uint32_t ndefer);
 __global__ void hg_fin_sort_small_kernel(const HgHit *hits, uint32_t *idx, const uint32_t *fill, uint32_t b_lo, uint32_t b_hi, uint32_t cap, uint32_t id_bits,
                                          uint32_t to_bits, uint32_t *kept_count, uint32_t *raw_total, uint32_t *big_list, uint32_t *big_count);
 __global__ void hg_fin_sort_big_kernel(const HgHit *hits, uint32_t *idx, const uint32_t *fill, const uint32_t *big_list, const uint32_t *big_count, uint32_t cap,
@@ -122,18 +124,18 @@ int HgScanner::create(std::shared_ptr<const HgDb> db, int device, HgScanner **ou
   s->view_.nslow_fast = db->nslow_fast;
   s->view_.fold_mask = db->fold_mask;
   s->view_.window_mask = db->window_mask;
-  HG_TRY(hgmem::dev_alloc(&s->d_counters_, HG_CNT_ALL_WORDS * 4, "d_counters_"), "alloc counters");
-  HG_TRY(hgmem::dev_alloc(&s->d_selected_, 16, "d_selected_"), "alloc counters");
-  HG_TRY(hgmem::dev_alloc(&s->d_final_, sizeof(HgTileBase), "d_final_"), "alloc state");
+  HG_TRY(hgmem::dev_alloc(&s->d_counters_, 64 * 4, "d_state_"), "alloc state");  // the state block (hg_engine.h, HG_ST_*)
+  s->d_fin_total_ = s->d_counters_ + HG_ST_FIN_TOTAL;
+  s->d_selected_ = s->d_counters_ + HG_ST_SELECTED;
+  s->d_final_ = reinterpret_cast<HgTileBase *>(s->d_counters_ + HG_ST_FINAL);
   HG_TRY(hgmem::dev_alloc(&s->d_pflags_, db->patterns.size() * 4 + 16, "d_pflags_"), "alloc pattern flags");
   HG_TRY(hgmem::host_alloc(&s->h_counters_, (HG_CNT_WORDS + 4 + HG_DEFER_SHARDS) * 4, "h_counters_"), "alloc pinned");
-  HG_TRY(hgmem::host_alloc(&s->h_final_, sizeof(HgTileBase), "h_final_"), "alloc pinned");
+  s->h_final_ = reinterpret_cast<HgTileBase *>(s->h_counters_ + HG_ST_FINAL);  // (the host copy of the state block)
   for (auto &ev : s->ev_) HG_TRY(hipEventCreate(&ev), "hipEventCreate");
   HG_TRY(hipStreamCreateWithFlags(&s->side_stream_, hipStreamNonBlocking), "hipStreamCreate");
 
   HG_TRY(hgmem::dev_alloc(&s->d_fin_fill_, HG_FIN_MAX_BUCKETS * 4, "d_fin_fill_"), "alloc finalize buckets");
   HG_TRY(hgmem::dev_alloc(&s->d_fin_kept_, HG_FIN_MAX_BUCKETS * 4, "d_fin_kept_"), "alloc finalize buckets");
-  HG_TRY(hgmem::dev_alloc(&s->d_fin_total_, 16, "d_fin_total_"), "alloc finalize buckets");
   HG_TRY(hgmem::dev_alloc(&s->d_fin_big_, HG_FIN_MAX_BUCKETS * 4, "d_fin_big_"), "alloc finalize buckets");
   // (the per-chunk events of the two-stream pipeline are created by the first scan that is large enough to use it: a
   // process that keeps dozens of scanners for small files would otherwise hold thousands of events for nothing)
@@ -145,11 +147,10 @@ int HgScanner::create(std::shared_ptr<const HgDb> db, int device, HgScanner **ou
 HgScanner::~HgScanner() {
   (void)hipSetDevice(device_);
   void *ptrs[] = {d_patterns_, d_pool_, d_factors_, d_windows_, d_bucket_, d_filter_, d_ext_, d_slow_, d_sums_, d_bases_, d_block_base_,
-                  d_final_, d_agg_, d_cands_, d_hits_raw_, d_hits_out_, d_aux_raw_, d_aux_out_,
-                  d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, d_keep_, d_counters_, d_selected_, d_temp_, d_seg_count_, d_pflags_, d_deferred_, d_defer_count_, d_seg_count2_, d_cands2_, d_disc_, d_bucket2_, d_windows2_};
+                  d_agg_, d_cands_, d_hits_raw_, d_hits_out_, d_aux_raw_, d_aux_out_,
+                  d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, d_keep_, d_counters_, d_temp_, d_seg_count_, d_pflags_, d_deferred_, d_defer_count_, d_seg_count2_, d_cands2_, d_disc_, d_bucket2_, d_windows2_};
   for (void *p : ptrs) hgmem::dev_free(p, "scanner");
   hgmem::host_free(h_counters_, "h_counters_");
-  hgmem::host_free(h_final_, "h_final_");
   for (auto &ev : ev_)
     if (ev) (void)hipEventDestroy(ev);
   for (int i = 0; i < kMaxChunks; i++) {
@@ -161,7 +162,6 @@ HgScanner::~HgScanner() {
 
   hgmem::dev_free(d_fin_fill_, "d_fin_fill_");
   hgmem::dev_free(d_fin_kept_, "d_fin_kept_");
-  hgmem::dev_free(d_fin_total_, "d_fin_total_");
   hgmem::dev_free(d_fin_big_, "d_fin_big_");
 }
 
@@ -238,7 +238,6 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   const uint64_t ntiles = (nbytes + HG_TILE_BYTES - 1) / HG_TILE_BYTES;
 #define HG_TRY(call, what) \
   if (fail((call), what)) return HG_ERR_HIP;
-  HG_TRY(hipMemsetAsync(d_counters_, 0, HG_CNT_ALL_WORDS * 4, stream), "memset counters");
   HG_TRY(hipEventRecord(ev_[0], stream), "event");
   // Bucketed emission + finalize (hg_fin_*): buckets of 2^fin_shift text bytes (4 KiB at least) by line start, at most
   // HG_FIN_MAX_BUCKETS of them, each a region of fin_cap records of the hit arrays.  The packed sort key must hold the line
@@ -255,11 +254,11 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   // one finalize after the last chunk: per chunk (beside the stream pass of the next one) it slowed the stream pass by more
   // than it took off the tail (measured: 8.33 vs 7.93 ms per 32 GiB); HG_FIN_PER_CHUNK=1 brings that variant back
   const bool fin_at_end = std::getenv("HG_FIN_PER_CHUNK") == nullptr;
-  if (bucketed) {
-    HG_TRY(hipMemsetAsync(d_fin_fill_, 0, fin_nb * 4, stream), "memset buckets");
-    HG_TRY(hipMemsetAsync(d_fin_total_, 0, 16, stream), "memset buckets");
-    HG_TRY(hipMemsetAsync(d_selected_, 0, 8, stream), "memset flags");
-  }
+  // one launch puts the device state in place (counters, cursors, finalize totals, tile-scan state, bucket fill levels, the
+  // first chunk's verified-occurrence counts)
+  hipLaunchKernelGGL(hg_reset_kernel, dim3(std::max<uint32_t>(1, std::min<uint32_t>((fin_nb + 255) / 256, 256))), dim3(256), 0, stream, d_counters_, static_cast<uint32_t>(HG_ST_ZERO_WORDS), d_final_,
+                     line_base, d_fin_fill_, bucketed ? fin_nb : 0u, d_defer_count_, static_cast<uint32_t>(HG_CONFIRM_MODES * HG_DEFER_SHARDS));
+  HG_TRY(hipGetLastError(), "reset launch");
 
   // Chunked pipeline (line mode, large buffers): the text is cut into tile-aligned chunks; the stream pass of chunk c+1
   // runs on the caller's stream while tile scan + verify + confirm of chunk c run on a side stream.  The stream pass
@@ -323,9 +322,6 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
     const uint32_t wgs_alone = std::getenv("HG_STREAM_WGS_PER_CU") ? wgs_shared : grid_for(static_cast<uint32_t>(stream_wgs_per_cu_));
     wgs = std::max(wgs_shared, wgs_alone);  // sizes the regrowth of the candidate segments
     hipStream_t side = piped ? side_stream_ : stream;
-    HgTileBase init{0, line_base};
-    *h_final_ = init;
-    HG_TRY(hipMemcpyAsync(d_final_, h_final_, sizeof(HgTileBase), hipMemcpyHostToDevice, stream), "upload scan state");
     if (piped && !ev_side_done_[0]) {
       for (int i = 0; i < kMaxChunks; i++) {
         HG_TRY(hipEventCreate(&ev_k1_begin_[i]), "hipEventCreate");
@@ -434,7 +430,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
             ca.list_of_mode[m] = db_->n_confirm_mode[m] ? next++ : 0;
             ca.list_spread[m] = std::max<uint32_t>(1, HG_DEFER_SHARDS / std::max<uint32_t>(1, db_->n_confirm_mode[m]));
           }
-          HG_TRY(hipMemsetAsync(d_defer_count_, 0, HG_CONFIRM_MODES * HG_DEFER_SHARDS * 4, side), "memset deferred counts");
+          if (c > 0) HG_TRY(hipMemsetAsync(d_defer_count_, 0, HG_CONFIRM_MODES * HG_DEFER_SHARDS * 4, side), "memset deferred counts");  // (chunk 0: hg_reset_kernel)
           hipLaunchKernelGGL(hg_verify_kernel, dim3(verify_blocks), dim3(256), 0, side, ca);
           if (fast_modes) hipLaunchKernelGGL(hg_confirm_fast_kernel, dim3(mode_blocks * fast_modes), dim3(HG_CONFIRM_THREADS), 0, side, ca, mode_blocks);
           if (db_->n_confirm_mode[3]) hipLaunchKernelGGL(hg_confirm_generic_kernel, dim3(mode_blocks), dim3(256), 0, side, ca);
@@ -480,19 +476,12 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       if (piped) HG_TRY(hipEventRecord(ev_side_done_[c], side), "event");
     }
     if (piped) HG_TRY(hipStreamWaitEvent(stream, ev_side_done_[nchunks - 1], 0), "stream wait");
-    if (!block_mode) HG_TRY(hipMemcpyAsync(h_final_, d_final_, sizeof(HgTileBase), hipMemcpyDeviceToHost, stream), "copy state");
   } else {
     HG_TRY(hipEventRecord(ev_[1], stream), "event");
     HG_TRY(hipEventRecord(ev_[2], stream), "event");
-    h_final_->cs = 0;
-    h_final_->L = line_base;
   }
-  HG_TRY(hipMemcpyAsync(h_counters_, d_counters_, HG_CNT_WORDS * 4, hipMemcpyDeviceToHost, stream), "copy counters");
-  if (bucketed) {
-    HG_TRY(hipMemcpyAsync(h_counters_ + HG_CNT_WORDS, d_fin_total_, 8, hipMemcpyDeviceToHost, stream), "copy count");  // kept, raw
-    HG_TRY(hipMemcpyAsync(h_counters_ + HG_CNT_WORDS + 2, d_selected_ + 1, 4, hipMemcpyDeviceToHost, stream), "copy flag");
-    HG_TRY(hipEventRecord(ev_[3], stream), "event");
-  }
+  HG_TRY(hipMemcpyAsync(h_counters_, d_counters_, HG_ST_WORDS * 4, hipMemcpyDeviceToHost, stream), "copy state");  // the whole state block in one copy
+  if (bucketed) HG_TRY(hipEventRecord(ev_[3], stream), "event");
   HG_TRY(hipStreamSynchronize(stream), "stream sync (scan kernels)");
   if (piped) {
     for (uint32_t c = 0; c < nchunks; c++) {
@@ -503,10 +492,10 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   }
 
   const uint64_t n_cands = h_counters_[HG_CNT_CANDS];
-  const uint64_t n_raw = bucketed ? h_counters_[HG_CNT_WORDS + 1] : h_counters_[HG_CNT_HITS];
+  const uint64_t n_raw = bucketed ? h_counters_[HG_ST_FIN_TOTAL + 1] : h_counters_[HG_CNT_HITS];
   const uint64_t cand_need = h_counters_[HG_CNT_CAND_NEED], hit_need = h_counters_[HG_CNT_HIT_NEED];
   const uint64_t defer_need = h_counters_[HG_CNT_DEFER_NEED];
-  const bool fin_overflow = bucketed && h_counters_[HG_CNT_WORDS + 2] != 0;  // a bucket beyond what one block sorts
+  const bool fin_overflow = bucketed && h_counters_[HG_ST_SELECTED + 1] != 0;  // a bucket beyond what one block sorts
   if (cand_need || defer_need || hit_need || fin_overflow || (!bucketed && n_raw > hit_cap_)) {
     // a private segment, a bucket or the compact hit array was too small: grow and let the caller repeat the pass
     if (cand_need || defer_need) {
@@ -583,13 +572,13 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
     HG_TRY(rocprim::exclusive_scan(d_temp_, tb, d_keep_, pos, 0u, n, rocprim::plus<uint32_t>(), stream), "scan");
     hipLaunchKernelGGL(hg_scatter_kernel, dim3(blocks), dim3(256), 0, stream, d_hits_raw_, d_aux_raw_, perm, d_keep_, pos, n, d_hits_out_, d_aux_out_, d_selected_);
     HG_TRY(hipGetLastError(), "finalize launch");
-    HG_TRY(hipMemcpyAsync(h_counters_ + HG_CNT_WORDS, d_selected_, 4, hipMemcpyDeviceToHost, stream), "copy count");
+    HG_TRY(hipMemcpyAsync(h_counters_ + HG_ST_SELECTED, d_selected_, 4, hipMemcpyDeviceToHost, stream), "copy count");
   }
   if (!bucketed) {
     HG_TRY(hipEventRecord(ev_[3], stream), "event");
     HG_TRY(hipStreamSynchronize(stream), "stream sync (finalize)");
   }
-  if (n) kept = h_counters_[HG_CNT_WORDS];
+  if (n) kept = bucketed ? h_counters_[HG_ST_FIN_TOTAL] : h_counters_[HG_ST_SELECTED];
   out->n_hits = kept;
   out->n_pieces = n_pieces;
   out->n_cands = n_cands;

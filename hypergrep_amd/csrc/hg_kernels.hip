@@ -1685,6 +1685,20 @@ __global__ __launch_bounds__(256) void hg_block_scan_kernel(HgConfirmArgs a, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// One launch puts the scanner's device state in place for a pass (it used to be half a dozen memsets and a host-to-device
+// copy, each a launch of its own in front of the first stream kernel): counters, tile cursors, finalize totals and flags
+// zeroed, the tile-scan state set to (carry-in line start 0, first line number), bucket fill levels and the
+// verified-occurrence counts zeroed.
+__global__ void hg_reset_kernel(uint32_t *state, uint32_t state_words, HgTileBase *final_state, uint64_t line_base, uint32_t *fill, uint32_t nb, uint32_t *defer_count,
+                                uint32_t ndefer) {
+  const uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  for (uint32_t i = i0; i < state_words; i += stride) state[i] = 0;
+  for (uint32_t i = i0; i < nb; i += stride) fill[i] = 0;
+  for (uint32_t i = i0; i < ndefer; i += stride) defer_count[i] = 0;
+  if (i0 == 0) *final_state = HgTileBase{0, line_base};
+}
+
+// ------------------------------------------------------------------------------------------------
 // Finalize, bucketed (the default): order by (line, id, to), SINGLEMATCH / duplicate rules, compaction.
 // The confirm passes put every hit straight into the bucket of its line's start (HitSink::push): a line's start position
 // grows with its number, so the buckets are in final order among themselves and all reports of one line sit in ONE bucket,
