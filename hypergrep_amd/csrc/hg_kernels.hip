@@ -588,7 +588,8 @@ void launch_one(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
 template <int L, bool W, int B>
 int blocks_one() {
   int n = 0;
-  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (hg_stream_kernel<L, W, B, HG_DEPTH_SHARED>), WG_THREADS, 0);
+  // (the launch that has the chip to itself decides how many workgroups a CU holds)
+  (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (hg_stream_kernel<L, W, B, (!W && !B && L <= 12) ? HG_DEPTH_ALONE : HG_DEPTH_SHARED>), WG_THREADS, 0);
   return n > 0 ? n : 1;
 }
 }  // namespace
