@@ -99,42 +99,55 @@ def main() -> None:
     db, sc = make_scanner(not args.no_tune, ids)
     stream = torch.cuda.current_stream().cuda_stream
 
-    # N > 1: the hit gather of step k runs on its own stream and overlaps the scan of step k + 1 (two buffer sets);
-    # the final synchronize of the timed region waits for every gather
+    # N > 1: the hit gather of step k runs on its own stream WHILE step k + 1 scans (two buffer sets).  The counts exchange of
+    # step k is enqueued right after its scan and read one step later (shard.CountExchange): no host stall per step; the
+    # gather of the last step is flushed before the timed region ends.
     comm_stream = torch.cuda.Stream(device=dev) if world > 1 else None
     hit_bufs: list = [None, None]
     recv_sets: list = [[], []]
     slot_free: list = [None, None]  # event: the gather that last used the slot has finished
+    pending: list = []              # (slot, hits copied, counts exchange, event: the copy into the slot is done)
     step_no = [0]
+
+    def flush_gather():
+        slot, n, counts, ready = pending.pop(0)
+        totals = counts.result()
+        hit_buf = hit_bufs[slot]
+        need = max(int(totals[:, 1].max()), 1)
+        if rank == 0 and (not recv_sets[slot] or recv_sets[slot][0].shape[0] < need):
+            recv_sets[slot] = [torch.empty((need + need // 8, 2), dtype=torch.int64, device=dev) for _ in range(world - 1)]
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(ready)
+            hit_buf[:n, 0] += shard.line_offset(totals, rank)  # shard-local line numbers -> global
+            shard.gather_hits(hit_buf[:n], totals, recv_sets[slot])
+            slot_free[slot] = comm_stream.record_event()
 
     def step():
         st = sc.scan(text.data_ptr(), nbytes, stream=stream)
         if world > 1:
             slot = step_no[0] & 1
             step_no[0] += 1
-            totals = shard.exchange_counts(st.n_lines, st.n_hits, dev)
-            # hit records (u64 line, u32 id, u32 to) -> a tensor, shard-local line numbers made global, sent to rank 0
-            need = max(int(totals[:, 1].max()), 1)
-            if hit_bufs[slot] is None or hit_bufs[slot].shape[0] < need:
+            counts = shard.CountExchange(dev).start(st.n_lines, st.n_hits)
+            if pending:
+                flush_gather()  # the previous step's hits travel while this step's results are post-processed and the next scan runs
+            if hit_bufs[slot] is None or hit_bufs[slot].shape[0] < st.n_hits:
                 if slot_free[slot] is not None:
                     slot_free[slot].synchronize()
-                hit_bufs[slot] = torch.empty((need + need // 8, 2), dtype=torch.int64, device=dev)
-                recv_sets[slot] = [torch.empty_like(hit_bufs[slot]) for _ in range(world - 1)] if rank == 0 else []
+                hit_bufs[slot] = torch.empty((st.n_hits + st.n_hits // 8 + 16, 2), dtype=torch.int64, device=dev)
             main = torch.cuda.current_stream()
             if slot_free[slot] is not None:
                 main.wait_event(slot_free[slot])
-            hit_buf = hit_bufs[slot]
-            n = sc.copy_hits_to(hit_buf.data_ptr(), st.n_hits, stream=stream)
-            hit_buf[:n, 0] += shard.line_offset(totals, rank)
-            ready = main.record_event()
-            with torch.cuda.stream(comm_stream):
-                comm_stream.wait_event(ready)
-                shard.gather_hits(hit_buf[:n], totals, recv_sets[slot])
-                slot_free[slot] = comm_stream.record_event()
+            n = sc.copy_hits_to(hit_bufs[slot].data_ptr(), st.n_hits, stream=stream)  # (u64 line, u32 id, u32 to) records
+            pending.append((slot, n, counts, main.record_event()))
         return st
+
+    def drain():
+        while pending:
+            flush_gather()
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -144,6 +157,7 @@ def main() -> None:
     for _ in range(args.steps):
         last = step()
         ms_stream.append(last.ms_stream)
+    drain()  # (the last step's gather)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -13,7 +13,7 @@
 #include <rocprim/rocprim.hpp>
 
 // kernels (hg_kernels.hip)
-void hg_launch_stream(const HgStreamArgs &a, uint32_t grid, hipStream_t stream);
+bool hg_launch_stream(const HgStreamArgs &a, uint32_t grid, hipStream_t stream);
 int hg_stream_blocks_per_cu(uint32_t filter_log2, uint32_t filter_wide, uint32_t dense);
 __global__ void hg_tile_reduce_kernel(const HgTileSum *sums, uint64_t tile_begin, uint64_t tile_end, uint64_t bs1, HgTileElem *agg);
 __global__ void hg_tile_spine_kernel(const HgTileElem *agg, uint32_t nblocks, uint64_t bs1, HgTileBase *block_base, HgTileBase *state);
@@ -365,7 +365,10 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       sa.alone = (c == 0 && wgs_c == wgs_alone && !std::getenv("HG_STREAM_WGS_PER_CU")) ? 1u : 0u;
       sa.counters = d_counters_;
       HG_TRY(hipEventRecord(piped ? ev_k1_begin_[c] : ev_[1], stream), "event");
-      hg_launch_stream(sa, wgs_c, stream);
+      if (!hg_launch_stream(sa, wgs_c, stream)) {
+        err_ = "no stream kernel for this database's filter size / mode";
+        return HG_ERR_ARG;
+      }
       HG_TRY(hipGetLastError(), "hg_stream_kernel launch");
       HG_TRY(hipEventRecord(piped ? ev_k1_end_[c] : ev_[2], stream), "event");
       if (piped) HG_TRY(hipStreamWaitEvent(side, ev_k1_end_[c], 0), "stream wait");

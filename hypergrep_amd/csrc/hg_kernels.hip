@@ -593,15 +593,16 @@ int blocks_one() {
   return n > 0 ? n : 1;
 }
 }  // namespace
-void hg_launch_stream(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
+// Returns false when no instantiation exists for the database's (filter size, mode): nothing was launched.
+bool hg_launch_stream(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
   if (a.filter_wide) {
     switch (a.filter_log2) {
       case 13: launch_one<13, true, 0>(a, grid, stream); break;
       case 14: launch_one<14, true, 0>(a, grid, stream); break;
       case 15: launch_one<15, true, 0>(a, grid, stream); break;
-      default: break;
+      default: return false;
     }
-    return;
+    return true;
   }
   if (a.dense == 1) {  // byte-aligned probing, a window at every byte
     switch (a.filter_log2) {
@@ -610,9 +611,9 @@ void hg_launch_stream(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) 
       case 13: launch_one<13, false, 1>(a, grid, stream); break;
       case 14: launch_one<14, false, 1>(a, grid, stream); break;
       case 15: launch_one<15, false, 1>(a, grid, stream); break;
-      default: break;
+      default: return false;
     }
-    return;
+    return true;
   }
   if (a.dense == 2) {  // ... at every second byte
     switch (a.filter_log2) {
@@ -621,9 +622,9 @@ void hg_launch_stream(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) 
       case 13: launch_one<13, false, 2>(a, grid, stream); break;
       case 14: launch_one<14, false, 2>(a, grid, stream); break;
       case 15: launch_one<15, false, 2>(a, grid, stream); break;
-      default: break;
+      default: return false;
     }
-    return;
+    return true;
   }
   switch (a.filter_log2) {
     case 11: launch_one<11, false, 0>(a, grid, stream); break;
@@ -631,8 +632,9 @@ void hg_launch_stream(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) 
     case 13: launch_one<13, false, 0>(a, grid, stream); break;
     case 14: launch_one<14, false, 0>(a, grid, stream); break;
     case 15: launch_one<15, false, 0>(a, grid, stream); break;
-    default: break;
+    default: return false;
   }
+  return true;
 }
 int hg_stream_blocks_per_cu(uint32_t filter_log2, uint32_t filter_wide, uint32_t dense) {
   if (filter_wide) return filter_log2 == 13 ? blocks_one<13, true, 0>() : (filter_log2 == 14 ? blocks_one<14, true, 0>() : blocks_one<15, true, 0>());
@@ -891,7 +893,8 @@ __global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t seg = blockIdx.x / HG_CONFIRM_SPLIT, sub = blockIdx.x % HG_CONFIRM_SPLIT;
   const HgCand *cseg = a.cands + static_cast<uint64_t>(seg) * a.cand_seg_cap;
-  const uint32_t n = a.seg_count[seg];
+  uint32_t n = a.seg_count[seg];
+  if (n > a.cand_seg_cap) n = a.cand_seg_cap;  // (never more than a segment holds, whatever the counter says)
   const uint32_t shard = blockIdx.x % HG_DEFER_SHARDS;
   const uint32_t fold = a.db.fold_mask;
   const uint64_t readable = (a.nbytes + 15) & ~15ull;  // the text buffer can be read up to here

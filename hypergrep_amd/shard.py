@@ -12,12 +12,39 @@ import torch.distributed as dist
 
 
 def exchange_counts(n_lines: int, n_hits: int, device) -> torch.Tensor:
-    """Returns an int64 tensor [world, 2] of every rank's (lines, hits)."""
-    world = dist.get_world_size()
-    mine = torch.tensor([n_lines, n_hits], dtype=torch.int64, device=device)
-    out = [torch.zeros(2, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(out, mine)
-    return torch.stack(out).cpu()
+    """Returns an int64 tensor [world, 2] of every rank's (lines, hits), on the host (blocks until the exchange is done)."""
+    return CountExchange(device).start(n_lines, n_hits).result()
+
+
+class CountExchange:
+    """The all_gather of (lines, hits) without a host stall: start() enqueues the collective and an asynchronous copy of its
+    result to pinned memory; result() is asked for one step LATER (the gather of step k's hits runs while step k + 1 scans),
+    when the copy has long finished.  On CPU tensors (gloo, the tests) everything is synchronous."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self._host = None
+        self._event = None
+
+    def start(self, n_lines: int, n_hits: int) -> "CountExchange":
+        world = dist.get_world_size()
+        mine = torch.tensor([n_lines, n_hits], dtype=torch.int64, device=self.device)
+        out = torch.zeros((world, 2), dtype=torch.int64, device=self.device)
+        dist.all_gather_into_tensor(out.view(-1), mine)
+        if self.device.type == "cuda":
+            self._host = torch.empty((world, 2), dtype=torch.int64, pin_memory=True)
+            self._host.copy_(out, non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record()
+            self._keep = out
+        else:
+            self._host = out
+        return self
+
+    def result(self) -> torch.Tensor:
+        if self._event is not None:
+            self._event.synchronize()
+        return self._host
 
 
 def line_offset(totals: torch.Tensor, rank: int) -> int:

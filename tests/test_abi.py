@@ -187,3 +187,45 @@ def test_reference_loader_accepts_the_face_a_artefact():
 
     if not torch.cuda.is_available():
         assert res["rc"] == 3 and res["rows"] == 0  # HYPERSCANNER_SCRATCH: no GPU, and no CPU path
+
+
+def test_compile_cache_hits_and_bound():
+    """The reference recompiles the database for every file (hyperscanner.c:296); here identical pattern sets share one
+    compiled database: a repeated set is a cache hit, and the cache holds at most 16 sets (least recently used evicted).
+    check_patterns() goes through the same cache and needs no GPU."""
+    import hypergrep_amd
+    from hypergrep_amd import device
+
+    before = device.faceb_stats()
+    assert hypergrep_amd.check_compatibility(["cache_probe_alpha", "beta[0-9]+"]) == 0
+    mid = device.faceb_stats()
+    assert mid["db_cache_misses"] == before["db_cache_misses"] + 1
+    assert hypergrep_amd.check_compatibility(["cache_probe_alpha", "beta[0-9]+"]) == 0
+    after = device.faceb_stats()
+    assert after["db_cache_hits"] == mid["db_cache_hits"] + 1 and after["db_cache_misses"] == mid["db_cache_misses"]
+    # same expressions, other flags or ids: a different database
+    assert hypergrep_amd.check_compatibility(["cache_probe_alpha", "beta[0-9]+"], flags=[14, 6]) == 0
+    assert device.faceb_stats()["db_cache_misses"] == after["db_cache_misses"] + 1
+    for i in range(20):
+        assert hypergrep_amd.check_compatibility([f"cache_filler_{i:02d}"]) == 0
+    full = device.faceb_stats()
+    assert full["db_cache_entries"] == 16
+    # the first set was evicted meanwhile: compiling it again is a miss; a rejected set is never cached
+    assert hypergrep_amd.check_compatibility(["cache_probe_alpha", "beta[0-9]+"]) == 0
+    assert device.faceb_stats()["db_cache_misses"] == full["db_cache_misses"] + 1
+    assert hypergrep_amd.check_compatibility(["(?<!x)y"]) == 4 and hypergrep_amd.check_compatibility(["(?<!x)y"]) == 4
+    assert device.faceb_stats()["db_cache_entries"] == 16
+
+
+def test_faceb_device_selection(monkeypatch):
+    """Concurrent hyperscan() calls shard files over the node's GPUs round-robin; HYPERGREP_DEVICE pins one (hg_shim.hip
+    checkout -> hg_faceb_next_device)."""
+    from hypergrep_amd import device
+
+    monkeypatch.delenv("HYPERGREP_DEVICE", raising=False)
+    first = device.faceb_next_device(8)
+    assert [device.faceb_next_device(8) for _ in range(16)] == [(first + 1 + i) % 8 for i in range(16)]
+    assert device.faceb_next_device(1) == 0 and device.faceb_next_device(0) == -1
+    monkeypatch.setenv("HYPERGREP_DEVICE", "5")
+    assert [device.faceb_next_device(8) for _ in range(4)] == [5, 5, 5, 5]
+    assert device.faceb_next_device(4) == 1  # (taken modulo the devices present)

@@ -885,3 +885,111 @@ def test_many_pattern_sets_through_the_file_api(torch_cuda):
     assert res["ok"] and res["sets"] == 48 and res["contexts_alive"] >= 40, res
     res = _run_gpu_cases("many-sets", {"HYPERGREP_POOL": "4"})
     assert res["ok"] and res["contexts_alive"] <= 4 and res["contexts_rebound"] >= 40, res
+
+
+# ------------------------------------------------------------------ BASELINE configs 1, 2 and 5 (config 3: above; config 4: 8 GPUs)
+def test_config1_one_literal_one_mib_through_grep(torch_cuda, tmp_path):
+    """BASELINE config 1: one literal pattern over a 1 MiB plaintext file through grep() (hypergrep/utils.py:147-231), the
+    whole drop-in path: file -> hyperscan() -> batches -> (1-based line number, decoded line) tuples."""
+    import hypergrep_amd
+    from hypergrep_amd import benchspec, device
+
+    patterns, needles, hpm = benchspec.c1_spec()
+    data = device.synth_host(1 << 20, benchspec.SEED_BASE + 1, needles, hpm)
+    path = tmp_path / "c1.log"
+    path.write_bytes(data)
+    rows, rc = hypergrep_amd.grep(str(path), patterns)
+    want_rc, want_rows, _ = oracle_py.scan_file(str(path), patterns)
+    assert rc == want_rc == 0
+    assert rows == [(ln + 1, line.decode()) for ln, _id, line in want_rows]
+    assert 50 < len(rows) < 200  # 1 % of ~9 500 lines
+    assert hypergrep_amd.grep(str(path), patterns, count_only=True) == (len(rows), 0)
+    assert _loaded_native()
+
+
+def test_config2_one_regex_four_gib(torch_cuda):
+    """BASELINE config 2: one regex (character class + bounded repeat) over 4 GiB of synthetic log on one GPU: exact line
+    count, strict order, idempotence, and the head of the text against the oracle."""
+    from hypergrep_amd import benchspec, device
+
+    torch = torch_cuda
+    patterns, needles, hpm = benchspec.c2_spec()
+    nbytes = 4 << 30
+    text = torch.empty(nbytes + 64, dtype=torch.uint8, device="cuda:0")
+    device.synth_device(text.data_ptr(), nbytes, benchspec.SEED_BASE + 2, needles, hpm)
+    torch.cuda.synchronize()
+    newlines = int((text[:nbytes] == 10).sum())
+    db = device.Database(patterns)
+    sc = device.Scanner(db, 0)
+
+    def run():
+        st = sc.scan(text.data_ptr(), nbytes)
+        buf = torch.empty((st.n_hits, 2), dtype=torch.int64, device="cuda:0")
+        assert sc.copy_hits_to(buf.data_ptr(), st.n_hits) == st.n_hits
+        torch.cuda.synchronize()
+        return st, buf
+
+    st, a = run()
+    assert st.n_lines == newlines + (0 if int(text[nbytes - 1]) == 10 else 1)
+    assert bool((a[1:, 0] > a[:-1, 0]).all())  # one id, SINGLEMATCH: one report per line, lines strictly increasing
+    assert 0.008 < st.n_hits / st.n_lines < 0.012
+    st2, b = run()
+    assert st2.n_hits == st.n_hits and bool((a == b).all())
+    head_n = 2 << 20
+    host = bytes(text[:head_n].cpu().numpy())
+    head_n = host.rfind(b"\n") + 1
+    want, nl = oracle_hits(host[:head_n], patterns)
+    got = [h[:3] for h in sc.hits(limit=len(want) + 16) if h[0] < nl]
+    assert got == [w[:3] for w in want]
+
+
+def test_config5_4096_literals_use_the_wide_filter(torch_cuda):
+    """BASELINE config 5 (single-GPU side): 4096 literals, 10 % of the lines hit.  The set needs the wide (two-cell, cuckoo)
+    LDS filter; 64 MiB against properties + the head against the oracle."""
+    import ctypes
+
+    from hypergrep_amd import benchspec, device
+
+    torch = torch_cuda
+    patterns, needles, hpm = benchspec.c5_spec()
+    ids = list(range(len(patterns)))
+    db = device.Database(patterns, ids=ids)
+    info = db.info()
+    assert info["n_patterns"] == 4096 and info["n_always_on"] == 0 and info["n_windows"] >= 4 * 4096
+    assert info["byte_windows"] == 0  # dword-aligned windows; > 14 000 of them: the wide filter (hg_compile.cpp build_filter)
+    nbytes = 64 << 20
+    text = torch.empty(nbytes + 64, dtype=torch.uint8, device="cuda:0")
+    device.synth_device(text.data_ptr(), nbytes, benchspec.SEED_BASE + 5, needles, hpm)
+    torch.cuda.synchronize()
+    sc = device.Scanner(db, 0)
+    st = sc.scan(text.data_ptr(), nbytes)
+    newlines = int((text[:nbytes] == 10).sum())
+    assert st.n_lines == newlines + (0 if int(text[nbytes - 1]) == 10 else 1)
+    assert 0.08 < st.n_hits / st.n_lines < 0.12
+    head_n = 1 << 20
+    host = bytes(text[:head_n].cpu().numpy())
+    head_n = host.rfind(b"\n") + 1
+    want, nl = oracle_hits(host[:head_n], patterns, ids=ids)
+    got = [h[:3] for h in sc.hits(limit=len(want) + 64) if h[0] < nl]
+    assert got == [w[:3] for w in want]
+    del ctypes
+
+
+def test_parallel_grep_with_worker_processes(torch_cuda, tmp_path, capsys):
+    """The --mp path of the reference's CLI (hypergrep/multiscanner.py:197-198, 538-543: a multiprocessing.Pool instead of
+    threads): here spawned workers, each initialising the GPU runtime itself.  Output equals the threaded run's."""
+    from hypergrep_amd import multiscanner
+
+    rng = random.Random(5)
+    files = []
+    for i in range(3):
+        p = tmp_path / f"f{i}.log"
+        p.write_bytes(regex_gen.random_text(rng, 400, maxlen=60) + b"needle_in_haystack %d\n" % i)
+        files.append(str(p))
+    rc_threads = multiscanner.parallel_grep(files, ["needle_in_haystack", "a[bc]+x"], ordered_results=True, with_file_name=True, with_line_number=True)
+    out_threads = capsys.readouterr().out
+    rc_procs = multiscanner.parallel_grep(files, ["needle_in_haystack", "a[bc]+x"], ordered_results=True, with_file_name=True, with_line_number=True,
+                                          use_multithreading=False)
+    out_procs = capsys.readouterr().out
+    assert rc_threads == rc_procs == 0
+    assert out_procs == out_threads and out_threads.count("needle_in_haystack") == 3
