@@ -1220,6 +1220,68 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
   return 0;
 }
 
+// Packs context-free single-word always-on expressions into shared state words (HgSlowGroup): first fit by node count.
+// Members move to the front of db.slow, group by group; a group of one is not worth its tables.
+void build_slow_groups(HgDb &db) {
+  db.groups.clear();
+  db.nslow_grouped = 0;
+  if (std::getenv("HG_NO_SLOW_GROUPS")) return;
+  struct Bin { std::vector<uint32_t> members; uint32_t nodes = 0; };
+  std::vector<Bin> bins;
+  for (uint32_t j = 0; j < db.nslow_fast; j++) {
+    const HgPattern &p = db.patterns[db.slow[j]];
+    if (!p.simple || p.nw != 1 || p.nnodes == 0) continue;
+    Bin *home = nullptr;
+    for (Bin &b : bins)
+      if (b.nodes + p.nnodes <= 32 && b.members.size() < HG_GROUP_MAX_MEMBERS) { home = &b; break; }
+    if (!home) { bins.emplace_back(); home = &bins.back(); }
+    home->members.push_back(db.slow[j]);
+    home->nodes += p.nnodes;
+  }
+  std::vector<uint32_t> grouped;
+  for (const Bin &b : bins) {
+    if (b.members.size() < 2) continue;
+    HgSlowGroup g{};
+    db.pool.resize((db.pool.size() + 3) & ~static_cast<size_t>(3), 0);  // (the wave stages reach[] with 16-byte loads)
+    g.reach_off = static_cast<uint32_t>(db.pool.size());
+    db.pool.resize(db.pool.size() + 256, 0);
+    g.follow_off = static_cast<uint32_t>(db.pool.size());
+    db.pool.resize(db.pool.size() + b.nodes, 0);
+    g.nnodes = b.nodes;
+    g.nmembers = static_cast<uint32_t>(b.members.size());
+    bool unbounded = false;
+    uint32_t shift = 0;
+    for (uint32_t m = 0; m < g.nmembers; m++) {
+      const HgPattern &p = db.patterns[b.members[m]];
+      g.member[m] = b.members[m];
+      g.acc[m] = p.acc_all << shift;
+      g.acc_all |= g.acc[m];
+      g.init_word |= p.init_word << shift;
+      if (p.single) g.single_mask |= 1u << m;
+      if (p.max_len == 0) unbounded = true;
+      g.max_len = std::max(g.max_len, p.max_len);
+      for (uint32_t c = 0; c < 256; c++) db.pool[g.reach_off + c] |= db.pool[p.reach_off + c] << shift;
+      for (uint32_t v = 0; v < p.nnodes; v++) db.pool[g.follow_off + shift + v] = db.pool[p.follow_off + v] << shift;
+      shift += p.nnodes;
+      grouped.push_back(b.members[m]);
+    }
+    if (unbounded) g.max_len = 0;
+    db.groups.push_back(g);
+  }
+  if (grouped.empty()) return;
+  // members first (group by group), then the other fast entries, then the rest: the order inside each class is kept
+  std::vector<uint32_t> rest_fast, rest_slow;
+  for (uint32_t j = 0; j < db.slow.size(); j++) {
+    const uint32_t pi = db.slow[j];
+    if (std::find(grouped.begin(), grouped.end(), pi) != grouped.end()) continue;
+    (j < db.nslow_fast ? rest_fast : rest_slow).push_back(pi);
+  }
+  db.slow = grouped;
+  db.slow.insert(db.slow.end(), rest_fast.begin(), rest_fast.end());
+  db.slow.insert(db.slow.end(), rest_slow.begin(), rest_slow.end());
+  db.nslow_grouped = static_cast<uint32_t>(grouped.size());
+}
+
 }  // namespace
 
 int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned *ids, unsigned n, HgDb **out,
@@ -1392,6 +1454,7 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
     auto two_words = [&](uint32_t pi) { return db->patterns[pi].nw <= 2; };  // bounded or not: an unbounded pattern's lead-in is the start of its line
     std::stable_partition(db->slow.begin(), db->slow.end(), two_words);
     db->nslow_fast = static_cast<uint32_t>(std::count_if(db->slow.begin(), db->slow.end(), two_words));
+    build_slow_groups(*db);
     // factors (needs the final fold mask); windows and filter tables are built from them
     for (unsigned i = 0; i < n; i++) {
       if (db->patterns[i].tier != 0) continue;

@@ -30,6 +30,8 @@ struct HgDb {
   std::vector<HgSlotInfo> ext;       // per filter slot: the window values in it and their neighbour-dword conditions (second-level check)
   std::vector<uint32_t> slow;        // indices of tier-1 (always-on) patterns, the nslow_fast bounded ones with <= 2 state words first
   uint32_t nslow_fast = 0;
+  std::vector<HgSlowGroup> groups;   // always-on expressions packed into shared state words (hg_db.h); their members are the
+  uint32_t nslow_grouped = 0;        // first nslow_grouped entries of `slow`, group by group
   uint32_t fold_mask = 0;            // 0x20202020 when any tier-0 pattern is case-insensitive
   uint32_t max_nw = 1;
   uint32_t max_id = 0;               // largest report id (sizes the sort key)

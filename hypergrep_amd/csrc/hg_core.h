@@ -56,6 +56,9 @@ struct HgDbView {
   uint32_t npatterns, nslow, fold_mask;
   uint32_t window_mask;  // 0xFFFFFFFF, or 0x00FFFFFF for 3-byte windows
   uint32_t nslow_fast;  // the first nslow_fast entries of `slow` have <= 2 state words: hg_always_on_fast_kernel takes them
+  uint32_t nslow_grouped;  // ... and the first nslow_grouped of those run as members of `groups` (HgSlowGroup), not one by one
+  uint32_t ngroups;
+  const HgSlowGroup *groups;
 };
 
 // 0x80 in every byte of x that is zero, exact (no borrow between bytes).

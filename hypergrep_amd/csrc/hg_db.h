@@ -97,6 +97,22 @@ struct HgWindow {
   uint32_t factor_off;  // factor index << 8 | off
 };
 
+// Several always-on expressions in ONE state word.  Context-free single-word automata whose nodes add up to <= 32 are
+// renumbered into one word (their follow sets stay disjoint), with the union of their reach / init tables: one pass of the
+// always-on kernel then advances all of them for the price of one, and only a match looks at which member accepted.
+constexpr uint32_t HG_GROUP_MAX_MEMBERS = 8;
+struct HgSlowGroup {
+  uint32_t reach_off;   // pool: reach[256] over the group's nodes
+  uint32_t follow_off;  // pool: follow[nnodes]
+  uint32_t nnodes, init_word, acc_all;
+  uint32_t max_len;      // longest match of any member, 0 = unbounded (some member is): the lead-in of the pass
+  uint32_t nmembers;
+  uint32_t single_mask;  // bit m: member m has HS_FLAG_SINGLEMATCH
+  uint32_t member[HG_GROUP_MAX_MEMBERS];  // pattern indices
+  uint32_t acc[HG_GROUP_MAX_MEMBERS];     // accepting nodes of each member
+};
+static_assert(sizeof(HgSlowGroup) == 96, "HgSlowGroup layout");
+
 HG_HD uint32_t hg_dot4(uint32_t v, uint32_t w) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_amdgcn_udot4(v, w, 0u, false);

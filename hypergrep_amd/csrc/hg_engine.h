@@ -139,7 +139,7 @@ class HgScanner {
   // database on device
   HgDbView view_{};
   std::shared_ptr<const HgDb> db_;
-  void *d_disc_ = nullptr, *d_bucket2_ = nullptr, *d_windows2_ = nullptr;
+  void *d_disc_ = nullptr, *d_bucket2_ = nullptr, *d_windows2_ = nullptr, *d_groups_ = nullptr;
   void *d_patterns_ = nullptr, *d_pool_ = nullptr, *d_factors_ = nullptr, *d_windows_ = nullptr, *d_bucket_ = nullptr,
        *d_filter_ = nullptr, *d_ext_ = nullptr, *d_slow_ = nullptr;
   // workspace

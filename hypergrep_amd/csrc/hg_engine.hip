@@ -110,6 +110,7 @@ int HgScanner::create(std::shared_ptr<const HgDb> db, int device, HgScanner **ou
   HG_TRY(upload(&s->d_filter_, db->filter, "d_filter_"), "upload filter");
   HG_TRY(upload(&s->d_ext_, db->ext, "d_ext_"), "upload filter conditions");
   HG_TRY(upload(&s->d_slow_, db->slow, "d_slow_"), "upload always-on list");
+  HG_TRY(upload(&s->d_groups_, db->groups, "d_groups_"), "upload always-on groups");
   s->view_.patterns = static_cast<const HgPattern *>(s->d_patterns_);
   s->view_.pool = static_cast<const uint32_t *>(s->d_pool_);
   s->view_.factors = static_cast<const HgFactor *>(s->d_factors_);
@@ -122,6 +123,9 @@ int HgScanner::create(std::shared_ptr<const HgDb> db, int device, HgScanner **ou
   s->view_.npatterns = static_cast<uint32_t>(db->patterns.size());
   s->view_.nslow = static_cast<uint32_t>(db->slow.size());
   s->view_.nslow_fast = db->nslow_fast;
+  s->view_.nslow_grouped = db->nslow_grouped;
+  s->view_.ngroups = static_cast<uint32_t>(db->groups.size());
+  s->view_.groups = static_cast<const HgSlowGroup *>(s->d_groups_);
   s->view_.fold_mask = db->fold_mask;
   s->view_.window_mask = db->window_mask;
   HG_TRY(hgmem::dev_alloc(&s->d_counters_, 64 * 4, "d_state_"), "alloc state");  // the state block (hg_engine.h, HG_ST_*)
@@ -148,7 +152,7 @@ HgScanner::~HgScanner() {
   (void)hipSetDevice(device_);
   void *ptrs[] = {d_patterns_, d_pool_, d_factors_, d_windows_, d_bucket_, d_filter_, d_ext_, d_slow_, d_sums_, d_bases_, d_block_base_,
                   d_agg_, d_cands_, d_hits_raw_, d_hits_out_, d_aux_raw_, d_aux_out_,
-                  d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, d_keep_, d_counters_, d_temp_, d_seg_count_, d_pflags_, d_deferred_, d_defer_count_, d_seg_count2_, d_cands2_, d_disc_, d_bucket2_, d_windows2_};
+                  d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, d_keep_, d_counters_, d_temp_, d_seg_count_, d_pflags_, d_deferred_, d_defer_count_, d_seg_count2_, d_cands2_, d_disc_, d_bucket2_, d_windows2_, d_groups_};
   for (void *p : ptrs) hgmem::dev_free(p, "scanner");
   hgmem::host_free(h_counters_, "h_counters_");
   for (auto &ev : ev_)

@@ -1087,7 +1087,8 @@ __device__ __forceinline__ void stage_tables(hgdev::lds_u32 *tab, const uint32_t
 // loop over the set bits, and the per-byte work is straight-line selects (newline / NUL / segment edges) with three rarely
 // taken branches (forced break, match to note, match ending with the line).  Same results as always_on_segment<1, *>.
 constexpr uint32_t CT_FU = CT_WORDS;              // fu[4][256]
-constexpr uint32_t AO_TAB_WORDS = CT_WORDS + 1024;  // a wave's table area in hg_always_on_fast_kernel
+constexpr uint32_t CT_MEMBER = CT_WORDS + 1024;     // member pattern indices [8] | accepting nodes of each [8] (a group, or one expression)
+constexpr uint32_t AO_TAB_WORDS = CT_WORDS + 1024 + 2 * HG_GROUP_MAX_MEMBERS;  // a wave's table area in hg_always_on_fast_kernel
 __device__ __forceinline__ void stage_follow_unions(hgdev::lds_u32 *tab, uint32_t nnodes, uint32_t lane) {
   // sixteen lanes per table; a lane fixes the low nibble of the index and walks the high one
   const uint32_t t = lane >> 4, j = lane & 15u;
@@ -1485,11 +1486,15 @@ __device__ __forceinline__ void always_on_segment1(const AlwaysOnCtx &a, const H
 
 // The same for automata without boundary conditions (`simple`), the bulk of the always-on tier: only the bytes [first, stop)
 // matter (no context byte at `stop`), the text comes a dword at a time, and the per-byte work is a dozen selects.
+// What the pass advances: one expression, or several packed into one state word (HgSlowGroup).
+struct AoUnit {
+  uint32_t init_word, acc_all, max_len, nmembers, single_mask;
+};
 template <int NT>  // follow-union tables in use: ceil(nodes / 8)
-__device__ __forceinline__ void always_on_simple(const AlwaysOnCtx &a, const HgPattern &p, uint32_t pi, const hgdev::lds_u32 *tab, uint64_t lo, uint64_t hi,
-                                                 uint64_t line_start, uint64_t bs1, uint32_t rank_lo) {
+__device__ __forceinline__ void always_on_simple(const AlwaysOnCtx &a, const AoUnit &p, const hgdev::lds_u32 *tab, uint64_t lo, uint64_t hi, uint64_t line_start,
+                                                 uint64_t bs1, uint32_t rank_lo) {
   if (lo >= hi) return;
-  const hgdev::lds_u32 *reach = tab + CT_REACH, *fu = tab + CT_FU;
+  const hgdev::lds_u32 *reach = tab + CT_REACH, *fu = tab + CT_FU, *member = tab + CT_MEMBER, *member_acc = tab + CT_MEMBER + HG_GROUP_MAX_MEMBERS;
   uint64_t q = line_start;  // first byte the automaton sees (always_on_segment)
   if (p.max_len && p.max_len <= HG_ALWAYS_ON_FAST_MAX_LEN) {
     const uint32_t lead = p.max_len - 1;
@@ -1501,7 +1506,6 @@ __device__ __forceinline__ void always_on_simple(const AlwaysOnCtx &a, const HgP
   const uint32_t first = static_cast<uint32_t>(q - base), own = static_cast<uint32_t>(lo - base), stop = static_cast<uint32_t>(hi - base);
   const uint32_t span = stop - first;
   const uint32_t I = p.init_word, acc = p.acc_all;
-  const uint32_t single = p.single ? 1u : 0u;
   constexpr uint32_t NO_BREAK = 0xFFFFFFFFu;
   const uint32_t bs1c = bs1 < 0x7FFFFFFFull ? static_cast<uint32_t>(bs1) : 0x7FFFFFFFu;
   uint32_t nb = NO_BREAK;  // next forced break, relative to base
@@ -1541,9 +1545,12 @@ __device__ __forceinline__ void always_on_simple(const AlwaysOnCtx &a, const HgP
       if (NT > 3) T |= fu[768 + (S >> 24)];
       const uint32_t Sn = c ? (T & rc[i]) : 0u;  // a NUL ends the scanned bytes (or is a skipped leading one): start afresh after it
       S = cons ? Sn : S;
-      if (cons && (Sn & acc) && !(single & reported)) {
-        reported = 1;  // (a match that ends in an earlier segment is that segment's to report; it also settles this line)
-        if (r >= own) always_on_note(a, pi, base + r + 1, rank);
+      if (cons && (Sn & acc)) {  // some member accepts (rare): which ones?  `reported`: bit m = member m has reported on this line
+        for (uint32_t m = 0; m < p.nmembers; m++) {
+          if (!(Sn & member_acc[m]) || ((p.single_mask & reported) >> m & 1u)) continue;
+          reported |= 1u << m;  // (a match that ends in an earlier segment is that segment's to report; it also settles this line)
+          if (r >= own) always_on_note(a, member[m], base + r + 1, rank);
+        }
       }
       const bool nl = cons && c == '\n';
       rank += (nl && r >= own) ? 1u : 0u;
@@ -1562,22 +1569,46 @@ __global__ __launch_bounds__(256) void hg_always_on_fast_kernel(HgConfirmArgs a)
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   hgdev::lds_u32 *tab = (hgdev::lds_u32 *)(&s_tab[0]) + wave * AO_TAB_WORDS;
-  // the tables of pattern j of the always-on list, staged by the wave
-  auto stage = [&](uint32_t j) {
-    const HgPattern &p = a.db.patterns[a.db.slow[j]];
-    __builtin_amdgcn_wave_barrier();  // the previous pattern's tables are no longer read
-    if (p.simple) stage_tables<false>(tab, a.db.pool, p, 1u, lane);
-    else stage_tables<true>(tab, a.db.pool, p, p.nw, lane);
+  // Units of the pass: the groups (several context-free expressions in one state word, HgSlowGroup) first, then the other
+  // entries of the always-on list one by one.  A unit's tables are staged by the wave.
+  const uint32_t ngroups = a.db.ngroups, nunits = ngroups + (a.db.nslow_fast - a.db.nslow_grouped);
+  auto stage = [&](uint32_t u) {
+    __builtin_amdgcn_wave_barrier();  // the previous unit's tables are no longer read
+    uint32_t nnodes;
+    bool one_word;
+    if (u < ngroups) {
+      const HgSlowGroup &g = a.db.groups[u];
+      const uint4 r0 = reinterpret_cast<const uint4 *>(a.db.pool + g.reach_off)[lane];  // (pool offsets of tables are multiples of 4 words)
+      tab[CT_REACH + 4 * lane + 0] = r0.x; tab[CT_REACH + 4 * lane + 1] = r0.y; tab[CT_REACH + 4 * lane + 2] = r0.z; tab[CT_REACH + 4 * lane + 3] = r0.w;
+      if (lane < g.nnodes) tab[CT_FOLLOW + lane] = a.db.pool[g.follow_off + lane];
+      if (lane < HG_GROUP_MAX_MEMBERS) {
+        tab[CT_MEMBER + lane] = g.member[lane];
+        tab[CT_MEMBER + HG_GROUP_MAX_MEMBERS + lane] = lane < g.nmembers ? g.acc[lane] : 0u;
+      }
+      nnodes = g.nnodes;
+      one_word = true;
+    } else {
+      const uint32_t pi = a.db.slow[a.db.nslow_grouped + (u - ngroups)];
+      const HgPattern &p = a.db.patterns[pi];
+      if (p.simple) stage_tables<false>(tab, a.db.pool, p, 1u, lane);
+      else stage_tables<true>(tab, a.db.pool, p, p.nw, lane);
+      if (lane == 0) {
+        tab[CT_MEMBER] = pi;
+        tab[CT_MEMBER + HG_GROUP_MAX_MEMBERS] = p.acc_all;
+      }
+      nnodes = p.nnodes;
+      one_word = p.nw == 1;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (p.nw == 1) {
-      stage_follow_unions(tab, p.nnodes, lane);
+    if (one_word) {
+      stage_follow_unions(tab, nnodes, lane);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
   };
-  const bool one_pattern = a.db.nslow_fast == 1;  // its tables stay staged for the whole kernel
-  if (one_pattern) stage(0);
+  const bool one_unit = nunits == 1;  // its tables stay staged for the whole kernel
+  if (one_unit) stage(0);
   // the verified-occurrence lists are free again (their confirm passes ran before this kernel): one segment per block
   const uint32_t list_cap = a.always_list_cap;
   const AlwaysOnCtx cx{a.text, a.nbytes, a.deferred + static_cast<uint64_t>(blockIdx.x) * list_cap, list_cap, (hgdev::lds_u32 *)(&s_n)};
@@ -1608,16 +1639,25 @@ __global__ __launch_bounds__(256) void hg_always_on_fast_kernel(HgConfirmArgs a)
     prev = __shfl_up(prev, 1, 64);
     if (lane == 0) prev = 0;
     const uint64_t line_start = prev ? tile_start + prev : tb.cs;
-    for (uint32_t j = 0; j < a.db.nslow_fast; j++) {  // wave-uniform
-      const uint32_t pi = a.db.slow[j];
+    for (uint32_t u = 0; u < nunits; u++) {  // wave-uniform
+      if (!one_unit) stage(u);
+      if (u < ngroups) {
+        const HgSlowGroup &g = a.db.groups[u];
+        const AoUnit unit{g.init_word, g.acc_all, g.max_len, g.nmembers, g.single_mask};
+        const uint32_t nt = (g.nnodes + 7u) >> 3;
+        if (nt <= 1) always_on_simple<1>(cx, unit, tab, lo, hi, line_start, a.bs1, rank_lo);
+        else if (nt == 2) always_on_simple<2>(cx, unit, tab, lo, hi, line_start, a.bs1, rank_lo);
+        else always_on_simple<4>(cx, unit, tab, lo, hi, line_start, a.bs1, rank_lo);
+        continue;
+      }
+      const uint32_t pi = a.db.slow[a.db.nslow_grouped + (u - ngroups)];
       const HgPattern &p = a.db.patterns[pi];
-      const bool simple = p.simple != 0;
-      if (!one_pattern) stage(j);
-      if (simple) {
+      if (p.simple) {
+        const AoUnit unit{p.init_word, p.acc_all, p.max_len, 1u, p.single ? 1u : 0u};
         const uint32_t nt = (p.nnodes + 7u) >> 3;  // wave-uniform
-        if (nt <= 1) always_on_simple<1>(cx, p, pi, tab, lo, hi, line_start, a.bs1, rank_lo);
-        else if (nt == 2) always_on_simple<2>(cx, p, pi, tab, lo, hi, line_start, a.bs1, rank_lo);
-        else always_on_simple<4>(cx, p, pi, tab, lo, hi, line_start, a.bs1, rank_lo);
+        if (nt <= 1) always_on_simple<1>(cx, unit, tab, lo, hi, line_start, a.bs1, rank_lo);
+        else if (nt == 2) always_on_simple<2>(cx, unit, tab, lo, hi, line_start, a.bs1, rank_lo);
+        else always_on_simple<4>(cx, unit, tab, lo, hi, line_start, a.bs1, rank_lo);
       }
       else if (p.nw == 1) always_on_segment1<false>(cx, p, pi, tab, lo, hi, line_start, a.bs1, rank_lo);
       else always_on_segment<2, false>(cx, p, pi, tab, lo, hi, line_start, a.bs1, rank_lo);

@@ -137,6 +137,9 @@ static HgDbView view_of(HgDb *db) {
   v.npatterns = db->patterns.size();
   v.nslow = db->slow.size();
   v.nslow_fast = db->nslow_fast;
+  v.nslow_grouped = 0;  // (the host replay runs every always-on expression on its own)
+  v.ngroups = 0;
+  v.groups = nullptr;
   v.fold_mask = db->fold_mask;
   v.window_mask = db->window_mask;
   return v;

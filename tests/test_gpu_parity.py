@@ -993,3 +993,33 @@ def test_parallel_grep_with_worker_processes(torch_cuda, tmp_path, capsys):
     out_procs = capsys.readouterr().out
     assert rc_threads == rc_procs == 0
     assert out_procs == out_threads and out_threads.count("needle_in_haystack") == 3
+
+
+def test_always_on_expressions_share_a_state_word(torch_cuda):
+    """Always-on expressions (no required literal of 3 bytes): the context-free single-word ones are packed into shared state
+    words (HgSlowGroup: one pass advances all of them) — mixed with SINGLEMATCH and all-matches flags, shared ids, an
+    expression with boundary conditions (runs on its own), an unbounded one (the group's lead-in becomes the line start),
+    a prefiltered one; small scan buffers force piece breaks through the packed automata."""
+    rng = random.Random(808)
+    pats = ["[a-z]+@[a-z]+", "x[0-9]+y", "[A-Z]{3}-[0-9]{4}:", "\\bq[a-z]*z\\b", "[0-9]+\\.[0-9]+", "=7", "needle_in_haystack_[0-9]+", "[_-][xyz]?[019]", "a{2,3}b"]
+    flags = [14, 6, 14, 14, 6, 14, 14, 6, 14]
+    ids = [0, 1, 1, 2, 3, 3, 4, 0, 5]
+    words = ["joe@host", "x12y", "ABC-1234:", "qz", "quiz", "3.14", "=7", "needle_in_haystack_42", "_x0", "-9", "aab", "aaab", "plain", "x1", "AB-12:", "q z"]
+    lines = []
+    for _ in range(3000):
+        n = rng.randint(0, 7)
+        lines.append(" ".join(rng.choice(words) if rng.random() < 0.4 else "".join(rng.choice("abqxyzABC019.@=-_: ") for _ in range(rng.randint(1, 9))) for _ in range(n)))
+    data = ("\n".join(lines) + "\n").encode()
+    data = data[:40000] + b"\0" + data[40000:70000] + b"x" * 3000 + b"12y joe@" + b"h" * 2500 + b"\n" + data[70000:]
+    for bs in (262140, 1000, 64):
+        want, nlines = oracle_hits(data, pats, flags, ids, buffer_size=bs)
+        got, stats = gpu_scan_buffer(torch_cuda, data, pats, flags, ids, buffer_size=bs)
+        assert stats.n_lines == nlines
+        assert got == want, bs
+        assert len(want) > 1000
+    # one group only (its tables stay staged), and a group next to a generic (multi-word) always-on expression
+    for sub in ([0, 1, 2], [0, 1, 4, 5]):
+        p, f, i = [pats[k] for k in sub], [flags[k] for k in sub], [ids[k] for k in sub]
+        want, nlines = oracle_hits(data, p, f, i)
+        got, stats = gpu_scan_buffer(torch_cuda, data, p, f, i)
+        assert got == want and stats.n_lines == nlines
