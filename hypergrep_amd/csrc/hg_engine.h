@@ -145,6 +145,8 @@ class HgScanner {
   // workspace
   uint64_t cap_tiles_ = 0;
   uint32_t cand_cap_ = 0, hit_cap_ = 0;
+  uint64_t chunk_limit_tiles_ = 0;   // pipeline chunks no larger than this (0: the default 8 GiB): halved when a chunk's candidates would not fit
+  uint32_t defer_spread_boost_ = 1;  // automaton confirm modes: lists per expression, raised when one expression's occurrences overflow its list
   bool hit_direct_ = false;  // the hits are too unevenly spread for equal per-block segments (HitSink::direct)
   HgTileSum *d_sums_ = nullptr;
   HgTileBase *d_bases_ = nullptr, *d_block_base_ = nullptr, *d_final_ = nullptr;
@@ -166,7 +168,7 @@ class HgScanner {
   HgTileBase *h_final_ = nullptr;   // pinned
   hipEvent_t ev_[4] = {nullptr, nullptr, nullptr, nullptr};
   // chunked pipeline: the stream pass of chunk c+1 overlaps the verify / confirm passes of chunk c
-  static constexpr int kMaxChunks = 16;
+  static constexpr int kMaxChunks = 64;
   hipStream_t side_stream_ = nullptr;
   hipEvent_t ev_k1_begin_[kMaxChunks] = {}, ev_k1_end_[kMaxChunks] = {}, ev_side_done_[kMaxChunks] = {};
   // bucketed emission + finalize (hg_fin_*): records per bucket / kept counts -> output positions / {kept, raw} totals;

@@ -278,7 +278,12 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
     uint64_t v = std::strtoull(env, nullptr, 10);
     if (!block_mode && v >= TS_BLOCK_TILES) chunk_tiles = std::max<uint64_t>(v / TS_BLOCK_TILES * TS_BLOCK_TILES, (ntiles + kMaxChunks - 1) / kMaxChunks / TS_BLOCK_TILES * TS_BLOCK_TILES + TS_BLOCK_TILES);
   }
+  if (!block_mode && chunk_limit_tiles_ && chunk_tiles > chunk_limit_tiles_) chunk_tiles = chunk_limit_tiles_;  // (a chunk's candidates did not fit before)
   nchunks = ntiles ? static_cast<uint32_t>((ntiles + chunk_tiles - 1) / chunk_tiles) : 1;
+  if (nchunks > static_cast<uint32_t>(kMaxChunks)) {
+    err_ = "the buffer needs more pipeline chunks than the scanner has: split the buffer";
+    return HG_ERR_ARG;
+  }
   std::vector<uint64_t> cut(nchunks + 1);  // chunk c = tiles [cut[c], cut[c + 1])
   for (uint32_t c = 0; c <= nchunks; c++) cut[c] = std::min<uint64_t>(static_cast<uint64_t>(c) * chunk_tiles, ntiles);
   if (const char *env = std::getenv("HG_CHUNK_WEIGHTS")) {  // experiment: relative chunk sizes, e.g. "10,10,8,4"
@@ -359,7 +364,8 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       sa.dense = db_->dense;
       sa.weights_c = db_->weights_c;
       // the chunk's workgroups draw runs of consecutive tiles from a cursor (hg_stream_kernel): two tiles per wave and draw
-      sa.cursor_slot = HG_CNT_CURSOR0 + c;
+      sa.cursor_slot = HG_CNT_CURSOR0 + c % 16;
+      if (c >= 16) HG_TRY(hipMemsetAsync(d_counters_ + sa.cursor_slot, 0, 4, stream), "memset cursor");  // (chunk c - 16 finished with it long ago)
       sa.ext = static_cast<const HgSlotInfo *>(d_ext_);
       sa.sums = d_sums_;
       sa.cands = cands;
@@ -435,7 +441,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
           for (uint32_t m = 0, next = 0; m < HG_CONFIRM_MODES; m++) {
             ca.mode_present[m] = (db_->n_confirm_mode[m] && ((mode_mask >> m) & 1u)) ? 1 : 0;
             ca.list_of_mode[m] = db_->n_confirm_mode[m] ? next++ : 0;
-            ca.list_spread[m] = std::max<uint32_t>(1, HG_DEFER_SHARDS / std::max<uint32_t>(1, db_->n_confirm_mode[m]));
+            ca.list_spread[m] = std::min<uint32_t>(HG_DEFER_SHARDS, std::max<uint32_t>(1, HG_DEFER_SHARDS / std::max<uint32_t>(1, db_->n_confirm_mode[m])) * defer_spread_boost_);
           }
           if (c > 0) HG_TRY(hipMemsetAsync(d_defer_count_, 0, HG_CONFIRM_MODES * HG_DEFER_SHARDS * 4, side), "memset deferred counts");  // (chunk 0: hg_reset_kernel)
           hipLaunchKernelGGL(hg_verify_kernel, dim3(verify_blocks), dim3(256), 0, side, ca);
@@ -506,14 +512,29 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   if (cand_need || defer_need || hit_need || fin_overflow || (!bucketed && n_raw > hit_cap_)) {
     // a private segment, a bucket or the compact hit array was too small: grow and let the caller repeat the pass
     if (cand_need || defer_need) {
+      // Candidate segments fill evenly (the stream workgroups draw their tiles on demand) and so do the position-sharded
+      // lists; a pattern-keyed list (automaton modes) overflows when ONE expression owns most occurrences: its occurrences
+      // are then spread over more lists instead of sizing every list for it.
+      if (defer_need && defer_spread_boost_ < HG_DEFER_SHARDS) defer_spread_boost_ *= 4;
       uint64_t want = std::max<uint64_t>((cand_need + cand_need / 4 + 64) * wgs, (defer_need + defer_need / 4 + 64) * HG_DEFER_SHARDS);
       want = std::max<uint64_t>(want, static_cast<uint64_t>(cand_cap_) * 2);
-      if (want > 0x7FFFFFF0u) {
-        err_ = "more than 2^31 candidates in one scan call: split the buffer";
-        return HG_ERR_ARG;
+      // The workspace holds ONE chunk's candidates (two buffer sets): when that would pass 2^30 records (16 GiB a set) the
+      // chunks get smaller instead — a text that fits in HBM always scans, a very dense one in more, smaller chunks.
+      uint64_t kCandLimit = 1ull << 30;
+      if (const char *env = std::getenv("HG_CAND_LIMIT")) kCandLimit = std::max<uint64_t>(1u << 16, std::strtoull(env, nullptr, 10));  // (tests)
+      if (want > kCandLimit) {
+        const uint64_t cur = (std::min<uint64_t>(chunk_tiles, ntiles) + TS_BLOCK_TILES - 1) / TS_BLOCK_TILES * TS_BLOCK_TILES;
+        if (block_mode || cur <= TS_BLOCK_TILES) {
+          err_ = "more than 2^30 candidates in 16 MiB of text: split the buffer";
+          return HG_ERR_ARG;
+        }
+        chunk_limit_tiles_ = std::max<uint64_t>(TS_BLOCK_TILES, cur / 2 / TS_BLOCK_TILES * TS_BLOCK_TILES);
+        want = std::min<uint64_t>(want / 2, kCandLimit);
       }
-      int rc = alloc_cands(want);
-      if (rc) return rc;
+      if (want > cand_cap_) {
+        int rc = alloc_cands(want);
+        if (rc) return rc;
+      }
     }
     if (bucketed && (hit_need || fin_overflow)) {
       // hit_need = the fullest bucket's demand.  Equal bucket regions are fine while the hits are spread; when one bucket
@@ -629,7 +650,7 @@ int HgScanner::scan_impl(const void *d_text, uint64_t nbytes, int buffer_size, u
     rc = run_once(static_cast<const uint8_t *>(d_text), nbytes, bs1, line_base, block_mode, stream, out, &overflow);
     if (rc) return rc;
     if (!overflow) break;
-    if (++reruns > 8) {
+    if (++reruns > 16) {
       err_ = "workspace kept overflowing";
       return HG_ERR_NOMEM;
     }

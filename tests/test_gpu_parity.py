@@ -1023,3 +1023,34 @@ def test_always_on_expressions_share_a_state_word(torch_cuda):
         want, nlines = oracle_hits(data, p, f, i)
         got, stats = gpu_scan_buffer(torch_cuda, data, p, f, i)
         assert got == want and stats.n_lines == nlines
+
+
+def test_dense_candidates_shrink_the_pipeline_chunks(torch_cuda, monkeypatch):
+    """A text whose every dword is a candidate: the workspace holds ONE pipeline chunk's candidates, and when that would pass
+    the limit (2^30 records; lowered here) the engine halves the chunks instead of failing with "split the buffer".
+    96 MiB of "aaaaaaaaa\\n" lines against the literal "aaaaaaaa": one hit per line, in order."""
+    from hypergrep_amd import device
+
+    torch = torch_cuda
+    line = b"aaaaaaaaa\n"
+    nbytes = 96 << 20
+    reps = nbytes // len(line)
+    nbytes = reps * len(line)
+    text = torch.frombuffer(bytearray(line * 4096), dtype=torch.uint8).cuda().repeat(reps // 4096 + 1)[:nbytes].contiguous()
+    pad = torch.zeros(nbytes + 64, dtype=torch.uint8, device="cuda:0")
+    pad[:nbytes] = text
+    torch.cuda.synchronize()
+    monkeypatch.setenv("HG_CAND_LIMIT", str(12 << 20))
+    monkeypatch.setenv("HG_CHUNK_TILES", str(4096))  # the pipeline starts with 64 MiB chunks
+    db = device.Database(["aaaaaaaa"])
+    sc = device.Scanner(db, 0)
+    st = sc.scan(pad.data_ptr(), nbytes)
+    assert st.n_lines == reps and st.n_hits == reps and st.reruns >= 2
+    assert st.stream_launches >= 3  # 96 MiB in chunks of 32 MiB or less
+    buf = torch.empty((st.n_hits, 2), dtype=torch.int64, device="cuda:0")
+    sc.copy_hits_to(buf.data_ptr(), st.n_hits)
+    torch.cuda.synchronize()
+    assert bool((buf[:, 0] == torch.arange(reps, device="cuda:0")).all())
+    assert bool((buf[:, 1] >> 32 == 8).all())  # `to` = 8, id 0
+    st2 = sc.scan(pad.data_ptr(), nbytes)
+    assert st2.n_hits == reps and st2.reruns == 0  # the scanner remembers the chunk size that fits
