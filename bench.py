@@ -275,7 +275,7 @@ def cpu_baseline(text, nbytes, patterns, ids, sc, target_seconds: float) -> dict
         return host[: host.rfind(b"\n") + 1]
 
     usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    threads = max(1, min(usable - 1, 64))
+    threads = max(1, min(usable - 1, 15))  # (a one-GPU box shares its host: 16 cores are this job's)
     real = _find_real_libhs()
     probe = lines_prefix(0, min(nbytes, 256 << 10))
     t0 = time.perf_counter()

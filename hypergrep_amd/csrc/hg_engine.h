@@ -36,7 +36,7 @@ enum { HG_CNT_CANDS = 0, HG_CNT_HITS = 1, HG_CNT_CAND_NEED = 2, HG_CNT_HIT_NEED 
 constexpr uint32_t HG_STREAM_GRAB = 2 * HG_STREAM_WG_WAVES_DEFAULT;  // tiles per draw of a stream workgroup: two per wave
 
 // Bucketed finalize (hg_fin_*): buckets of the final ordering and the largest bucket one wave sorts in LDS.
-constexpr uint32_t HG_FIN_MAX_BUCKETS = 1u << 16;
+constexpr uint32_t HG_FIN_MAX_BUCKETS = 1u << 20;
 constexpr uint32_t HG_FIN_BUCKET_CAP = 4096;
 
 // Threads of a confirm block: its LDS (the per-lane follow tables of the one-word automata, 128 B per lane) decides how many
@@ -94,6 +94,7 @@ struct HgConfirmArgs {
   uint32_t *bucket_fill;
   uint32_t *counters;
 };
+constexpr uint32_t HG_HIT_REL_SHIFT = 40;  // raw bucketed records: line_no (< 2^40) | line start inside the bucket (< 2^24) << 40
 constexpr uint32_t HG_HIT_SINGLE_BIT = 0x80000000u;  // raw bucketed records: bit 31 of `to` = the expression has HS_FLAG_SINGLEMATCH (`to` < 2^31)
 
 struct HgScanOutput {
@@ -170,11 +171,13 @@ class HgScanner {
   // chunked pipeline: the stream pass of chunk c+1 overlaps the verify / confirm passes of chunk c
   static constexpr int kMaxChunks = 64;
   hipStream_t side_stream_ = nullptr;
+  hipEvent_t ev_fin_early_ = nullptr;  // the finalize of the earlier chunks' buckets (beside the last chunk's side passes) is done
   hipEvent_t ev_k1_begin_[kMaxChunks] = {}, ev_k1_end_[kMaxChunks] = {}, ev_side_done_[kMaxChunks] = {};
   // bucketed emission + finalize (hg_fin_*): records per bucket / kept counts -> output positions / {kept, raw} totals;
   // fin_fallback_: a bucket outgrew what one block sorts, the compact array + library sort is used from then on
   uint32_t *d_fin_fill_ = nullptr, *d_fin_kept_ = nullptr, *d_fin_total_ = nullptr, *d_fin_big_ = nullptr;
   bool fin_fallback_ = false;
+  uint64_t fin_expect_hits_ = 0;  // raw hits of the last pass: the next one picks its bucket count for ~24 records a bucket
   uint32_t *d_seg_count2_ = nullptr;  // second set for double buffering
   HgCand *d_cands2_ = nullptr;
 };

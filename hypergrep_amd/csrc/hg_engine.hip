@@ -137,6 +137,7 @@ int HgScanner::create(std::shared_ptr<const HgDb> db, int device, HgScanner **ou
   s->h_final_ = reinterpret_cast<HgTileBase *>(s->h_counters_ + HG_ST_FINAL);  // (the host copy of the state block)
   for (auto &ev : s->ev_) HG_TRY(hipEventCreate(&ev), "hipEventCreate");
   HG_TRY(hipStreamCreateWithFlags(&s->side_stream_, hipStreamNonBlocking), "hipStreamCreate");
+  HG_TRY(hipEventCreateWithFlags(&s->ev_fin_early_, hipEventDisableTiming), "hipEventCreate");
 
   HG_TRY(hgmem::dev_alloc(&s->d_fin_fill_, HG_FIN_MAX_BUCKETS * 4, "d_fin_fill_"), "alloc finalize buckets");
   HG_TRY(hgmem::dev_alloc(&s->d_fin_kept_, HG_FIN_MAX_BUCKETS * 4, "d_fin_kept_"), "alloc finalize buckets");
@@ -163,6 +164,7 @@ HgScanner::~HgScanner() {
     if (ev_side_done_[i]) (void)hipEventDestroy(ev_side_done_[i]);
   }
   if (side_stream_) (void)hipStreamDestroy(side_stream_);
+  if (ev_fin_early_) (void)hipEventDestroy(ev_fin_early_);
 
   hgmem::dev_free(d_fin_fill_, "d_fin_fill_");
   hgmem::dev_free(d_fin_kept_, "d_fin_kept_");
@@ -244,20 +246,24 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   if (fail((call), what)) return HG_ERR_HIP;
   HG_TRY(hipEventRecord(ev_[0], stream), "event");
   // Bucketed emission + finalize (hg_fin_*): buckets of 2^fin_shift text bytes (4 KiB at least) by line start, at most
-  // HG_FIN_MAX_BUCKETS of them, each a region of fin_cap records of the hit arrays.  The packed sort key must hold the line
-  // field before the line count is known: it is sized for one line per byte.
+  // HG_FIN_MAX_BUCKETS of them, each a region of fin_cap records of the hit arrays.
   const uint32_t id_bits = bits_for(static_cast<uint64_t>(db_->max_id) + 1), to_bits = bits_for(bs1 + 1);
+  // As many buckets as give ~30-50 records each (one wave orders up to 64 in registers; larger buckets go through LDS): from
+  // the last pass's hits, else one hit per 8 KiB of text as a first guess.
   uint32_t fin_shift = 12, fin_nb = 1;
   if (nbytes) {
-    while (((nbytes - 1) >> fin_shift) >= HG_FIN_MAX_BUCKETS) fin_shift++;
+    const uint64_t expect = std::max<uint64_t>(fin_expect_hits_, nbytes >> 13);
+    uint64_t want_nb = 1;
+    while (want_nb * 48 < expect && want_nb < HG_FIN_MAX_BUCKETS) want_nb <<= 1;
+    while (((nbytes - 1) >> fin_shift) >= want_nb) fin_shift++;
     fin_nb = static_cast<uint32_t>((nbytes - 1) >> fin_shift) + 1;
   }
   const uint32_t fin_cap = hit_cap_ / fin_nb;
-  const bool bucketed = ntiles && fin_cap && bits_for(line_base + nbytes + 1) + id_bits + to_bits + 1 <= 64 && !fin_fallback_ && !std::getenv("HG_NO_BUCKET_FINALIZE");
+  // (sort key of a bucket: line start inside the bucket | id | to | single; the raw records carry that start in the top
+  // 24 bits of the line number, so line numbers must stay below 2^40)
+  const bool bucketed = ntiles && fin_cap && fin_shift <= 64 - HG_HIT_REL_SHIFT && fin_shift + id_bits + to_bits + 1 <= 64 &&
+                        bits_for(line_base + nbytes + 1) <= HG_HIT_REL_SHIFT && !fin_fallback_ && !std::getenv("HG_NO_BUCKET_FINALIZE");
   uint32_t fin_done = 0;  // buckets finalized so far
-  // one finalize after the last chunk: per chunk (beside the stream pass of the next one) it slowed the stream pass by more
-  // than it took off the tail (measured: 8.33 vs 7.93 ms per 32 GiB); HG_FIN_PER_CHUNK=1 brings that variant back
-  const bool fin_at_end = std::getenv("HG_FIN_PER_CHUNK") == nullptr;
   // one launch puts the device state in place (counters, cursors, finalize totals, tile-scan state, bucket fill levels, the
   // first chunk's verified-occurrence counts)
   hipLaunchKernelGGL(hg_reset_kernel, dim3(std::max<uint32_t>(1, std::min<uint32_t>((fin_nb + 255) / 256, 256))), dim3(256), 0, stream, d_counters_, static_cast<uint32_t>(HG_ST_ZERO_WORDS), d_final_,
@@ -342,6 +348,22 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       HG_TRY(hipEventRecord(ev_side_done_[kMaxChunks - 1], stream), "event");
       HG_TRY(hipStreamWaitEvent(side, ev_side_done_[kMaxChunks - 1], 0), "stream wait");
     }
+    // finalize of the buckets [lo, hi) on stream `s`: order each bucket, report rules, positions, gather (hg_fin_*)
+    auto launch_fin = [&](hipStream_t s, uint32_t lo, uint32_t hi) -> int {
+      if (hi <= lo) return HG_OK;
+      const uint32_t nbk = hi - lo, cu = static_cast<uint32_t>(num_cus_);
+      HG_TRY(hipMemsetAsync(d_fin_total_ + 2, 0, 4, s), "memset work list");  // (large buckets of this range)
+      hipLaunchKernelGGL(hg_fin_sort_small_kernel, dim3(std::min<uint32_t>((nbk + 3) / 4, cu * 8)), dim3(256), 0, s, d_hits_raw_, d_perm_a_, d_fin_fill_, lo, hi, fin_cap, id_bits, to_bits,
+                         d_fin_kept_, d_fin_total_ + 1, d_fin_big_, d_fin_total_ + 2);
+      hipLaunchKernelGGL(hg_fin_sort_big_kernel, dim3(std::min<uint32_t>(nbk, cu * 3)), dim3(256), 0, s, d_hits_raw_, d_perm_a_, d_fin_fill_, d_fin_big_, d_fin_total_ + 2, fin_cap, id_bits,
+                         to_bits, d_fin_kept_, d_fin_total_ + 1, d_selected_ + 1);
+      hipLaunchKernelGGL(hg_fin_scan_kernel, dim3(1), dim3(1024), 0, s, d_fin_kept_, lo, hi, d_fin_total_);
+      hipLaunchKernelGGL(hg_fin_gather_kernel, dim3(std::min<uint32_t>((nbk + 3) / 4, cu * 8)), dim3(256), 0, s, d_hits_raw_, d_aux_raw_, d_perm_a_, d_fin_kept_, d_fin_total_, lo, hi, fin_cap,
+                         d_hits_out_, d_aux_out_);
+      HG_TRY(hipGetLastError(), "finalize launch");
+      return HG_OK;
+    };
+    bool fin_early = false;  // the buckets of all chunks but the last were finalized beside the last chunk's side passes
     for (uint32_t c = 0; c < nchunks; c++) {
       const uint64_t t0 = cut[c], t1 = cut[c + 1];
       const uint32_t wgs_c = c == 0 ? wgs_alone : wgs_shared;
@@ -382,6 +404,21 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       HG_TRY(hipGetLastError(), "hg_stream_kernel launch");
       HG_TRY(hipEventRecord(piped ? ev_k1_end_[c] : ev_[2], stream), "event");
       if (piped) HG_TRY(hipStreamWaitEvent(side, ev_k1_end_[c], 0), "stream wait");
+      if (piped && bucketed && c + 1 == nchunks && c >= 1 && !std::getenv("HG_NO_EARLY_FINALIZE")) {
+        // The last stream launch is queued.  Behind it, on this stream, the buckets that the earlier chunks have completed
+        // are finalized WHILE the side stream works through the last chunk's verify / confirm passes (both have the chip to
+        // themselves by then); only the last chunk's buckets remain for after those.  (Finalizing a chunk's buckets beside
+        // the NEXT chunk's stream pass was tried: it slowed the stream pass by more than it saved.)
+        const uint64_t prev_end = std::min<uint64_t>(t0 << HG_TILE_SHIFT, nbytes);  // a later hit's line starts less than bs1 bytes before it
+        const uint32_t lim = static_cast<uint32_t>(std::min<uint64_t>((prev_end > bs1 ? prev_end - bs1 : 0) >> fin_shift, fin_nb));
+        if (lim > fin_done) {
+          HG_TRY(hipStreamWaitEvent(stream, ev_side_done_[c - 1], 0), "stream wait");  // the earlier chunks' hits are all in their buckets
+          if (int rc = launch_fin(stream, fin_done, lim)) return rc;
+          HG_TRY(hipEventRecord(ev_fin_early_, stream), "event");
+          fin_done = lim;
+          fin_early = true;
+        }
+      }
 
       HgConfirmArgs ca{};
       ca.text = text;
@@ -465,26 +502,10 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
           HG_TRY(hipGetLastError(), "hg_always_on_kernel launch");
         }
       }
-      if (bucketed) {
-        // the buckets no later chunk can add to: a hit found past this chunk's end lies in a piece that starts less than bs1
-        // bytes before it
-        const uint64_t end_byte = std::min<uint64_t>(t1 << HG_TILE_SHIFT, nbytes);
-        uint32_t lim = fin_nb;
-        if (c + 1 < nchunks) lim = fin_at_end ? 0u : static_cast<uint32_t>(std::min<uint64_t>((end_byte > bs1 ? end_byte - bs1 : 0) >> fin_shift, fin_nb));
-        if (lim > fin_done) {
-          const uint32_t nbk = lim - fin_done;
-          const uint32_t cu = static_cast<uint32_t>(num_cus_);
-          HG_TRY(hipMemsetAsync(d_fin_total_ + 2, 0, 4, side), "memset work list");  // (big buckets of this range)
-          hipLaunchKernelGGL(hg_fin_sort_small_kernel, dim3(std::min<uint32_t>((nbk + 3) / 4, cu * 8)), dim3(256), 0, side, d_hits_raw_, d_perm_a_, d_fin_fill_, fin_done, lim, fin_cap,
-                             id_bits, to_bits, d_fin_kept_, d_fin_total_ + 1, d_fin_big_, d_fin_total_ + 2);
-          hipLaunchKernelGGL(hg_fin_sort_big_kernel, dim3(std::min<uint32_t>(nbk, cu * 3)), dim3(256), 0, side, d_hits_raw_, d_perm_a_, d_fin_fill_, d_fin_big_, d_fin_total_ + 2, fin_cap,
-                             id_bits, to_bits, d_fin_kept_, d_fin_total_ + 1, d_selected_ + 1);
-          hipLaunchKernelGGL(hg_fin_scan_kernel, dim3(1), dim3(1024), 0, side, d_fin_kept_, fin_done, lim, d_fin_total_);
-          hipLaunchKernelGGL(hg_fin_gather_kernel, dim3(std::min<uint32_t>((nbk + 3) / 4, cu * 8)), dim3(256), 0, side, d_hits_raw_, d_aux_raw_, d_perm_a_, d_fin_kept_, d_fin_total_,
-                             fin_done, lim, fin_cap, d_hits_out_, d_aux_out_);
-          HG_TRY(hipGetLastError(), "finalize launch");
-          fin_done = lim;
-        }
+      if (bucketed && c + 1 == nchunks) {  // the side passes of the last chunk are queued: order what is left
+        if (fin_early) HG_TRY(hipStreamWaitEvent(side, ev_fin_early_, 0), "stream wait");  // (shared totals / work list: one range at a time)
+        if (int rc = launch_fin(side, fin_done, fin_nb)) return rc;
+        fin_done = fin_nb;
       }
       if (piped) HG_TRY(hipEventRecord(ev_side_done_[c], side), "event");
     }
@@ -541,7 +562,8 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       // holds thousands of them (every match end of an all-matches expression on one long line) the scanner leaves bucketed
       // emission for good: compact array + library sort.
       const uint64_t want = (hit_need + hit_need / 4 + 16) * fin_nb;
-      if (fin_overflow || hit_need > HG_FIN_BUCKET_CAP || want > (64ull << 20)) {
+      fin_expect_hits_ = std::max<uint64_t>(fin_expect_hits_ * 2, n_raw);  // (more, smaller buckets next time)
+      if (fin_overflow || hit_need > HG_FIN_BUCKET_CAP || want > (128ull << 20)) {
         fin_fallback_ = true;
       } else {
         int rc = alloc_hits(std::max<uint64_t>(want, static_cast<uint64_t>(hit_cap_) * 2));
@@ -570,6 +592,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
     return HG_OK;
   }
 
+  fin_expect_hits_ = n_raw;
   uint64_t n_pieces = block_mode ? 1 : h_final_->L - line_base + (nbytes > h_final_->cs ? hg_pieces(nbytes - h_final_->cs, bs1) : 0);
   uint32_t n = static_cast<uint32_t>(n_raw);
   uint32_t kept = 0;

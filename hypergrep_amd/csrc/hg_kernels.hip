@@ -790,7 +790,10 @@ struct HitSink {
       const uint32_t slot = atomicAdd(&a.bucket_fill[b], 1u);
       if (slot < a.bucket_cap) {
         const uint64_t at = static_cast<uint64_t>(b) * a.bucket_cap + slot;
-        a.hits[at] = HgHit{line_no, id, to | (single ? HG_HIT_SINGLE_BIT : 0u)};
+        // raw record: the line's start inside its bucket rides in the top bits of the line number — it orders the bucket's
+        // lines like the line number does, in far fewer key bits (hg_fin_*; the gather strips both extras again)
+        const uint64_t rel = start & ((1ull << a.bucket_shift) - 1ull);
+        a.hits[at] = HgHit{line_no | (rel << HG_HIT_REL_SHIFT), id, to | (single ? HG_HIT_SINGLE_BIT : 0u)};
         a.aux[at] = HgHitAux{start, len, pattern};
       } else {
         atomicMax(&a.counters[HG_CNT_HIT_NEED], slot + 1u);  // the engine grows the buckets (or leaves bucketed emission) and repeats the pass
@@ -1752,8 +1755,10 @@ __global__ void hg_reset_kernel(uint32_t *state, uint32_t state_words, HgTileBas
 // the last chunk's buckets are finalized after the last scan kernel; no library sort, no host round trip in between.
 // A bucket larger than HG_FIN_BUCKET_CAP (thousands of reports in one bucket: every match end of an all-matches expression
 // on a long line) raises a flag and the engine repeats the pass with the compact array + library sort (hg_key/keep/scatter).
+// key = line start inside the bucket | id | to | single (field widths id_bits / to_bits): the order of (line, id, to)
 __device__ __forceinline__ uint64_t fin_key(const HgHit &h, uint32_t id_bits, uint32_t to_bits) {
   HgHit c = h;
+  c.line_no = h.line_no >> HG_HIT_REL_SHIFT;
   c.to &= ~HG_HIT_SINGLE_BIT;
   return hg_sort_key_packed(c, (h.to & HG_HIT_SINGLE_BIT) != 0, id_bits, to_bits);
 }
@@ -1766,8 +1771,19 @@ __global__ __launch_bounds__(256) void hg_fin_sort_small_kernel(const HgHit *hit
   const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = (gridDim.x * blockDim.x) >> 6;
   const uint32_t group_shift = to_bits + 1;
   uint32_t seen = 0;
-  for (uint32_t b = b_lo + wave; b < b_hi; b += waves) {
-    uint32_t n = fill[b];
+  // A bucket's fill level and its first 64 records are loaded TOGETHER (lanes past the fill level read records of the same
+  // region that are simply not used), and one bucket ahead: the loads of bucket b + waves are in flight while bucket b is
+  // ordered.  Per bucket the wave then pays the sorting network, not two memory round trips.
+  const HgHit none{0, 0, 0};
+  uint32_t b = b_lo + wave;
+  uint32_t n_next = b < b_hi ? fill[b] : 0u;
+  HgHit h_next = (b < b_hi && lane < cap) ? hits[static_cast<uint64_t>(b) * cap + lane] : none;
+  for (; b < b_hi; b += waves) {
+    uint32_t n = n_next;
+    const HgHit h = h_next;
+    const uint32_t bn = b + waves;
+    n_next = bn < b_hi ? fill[bn] : 0u;
+    h_next = (bn < b_hi && lane < cap) ? hits[static_cast<uint64_t>(bn) * cap + lane] : none;
     if (n > cap) n = cap;  // (overflowed: the pass is repeated anyway)
     if (n > 64) {  // hg_fin_sort_big_kernel's: noted in its work list
       if (lane == 0) big_list[atomicAdd(big_count, 1u)] = b;
@@ -1779,7 +1795,7 @@ __global__ __launch_bounds__(256) void hg_fin_sort_small_kernel(const HgHit *hit
     }
     seen += n;
     const uint32_t b0 = b * cap;
-    uint64_t k = lane < n ? fin_key(hits[b0 + lane], id_bits, to_bits) : ~0ull;  // (padding sorts last; a real key never has all bits set)
+    uint64_t k = lane < n ? fin_key(h, id_bits, to_bits) : ~0ull;  // (padding sorts last; a real key never has all bits set)
     uint32_t x = b0 + lane;
     if (n > 1) {
 #pragma unroll
@@ -1926,12 +1942,24 @@ __global__ __launch_bounds__(HG_FIN_SCAN_THREADS) void hg_fin_scan_kernel(uint32
 __global__ void hg_fin_gather_kernel(const HgHit *hits, const HgHitAux *aux, const uint32_t *idx, const uint32_t *kept_base, const uint32_t *total, uint32_t b_lo,
                                      uint32_t b_hi, uint32_t cap, HgHit *oh, HgHitAux *oa) {
   const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = (gridDim.x * blockDim.x) >> 6;
-  for (uint32_t b = b_lo + wave; b < b_hi; b += waves) {
-    const uint32_t k0 = kept_base[b], k1 = b + 1 < b_hi ? kept_base[b + 1] : *total, b0 = b * cap;
-    for (uint32_t i = lane; i < k1 - k0; i += 64) {
-      const uint32_t src = idx[b0 + i];
+  // (one bucket ahead, like the sort: positions and the first 64 record indices of bucket b + waves are in flight while
+  // bucket b's records move)
+  auto base_of = [&](uint32_t b) { return b < b_hi ? kept_base[b] : *total; };
+  uint32_t b = b_lo + wave;
+  uint32_t k0_next = b < b_hi ? kept_base[b] : 0u, k1_next = b < b_hi ? base_of(b + 1) : 0u;
+  uint32_t src_next = (b < b_hi && lane < cap) ? idx[b * cap + lane] : 0u;
+  for (; b < b_hi; b += waves) {
+    const uint32_t k0 = k0_next, n = k1_next - k0, b0 = b * cap;
+    const uint32_t src0 = src_next;
+    const uint32_t bn = b + waves;
+    k0_next = bn < b_hi ? kept_base[bn] : 0u;
+    k1_next = bn < b_hi ? base_of(bn + 1) : 0u;
+    src_next = (bn < b_hi && lane < cap) ? idx[bn * cap + lane] : 0u;
+    for (uint32_t i = lane; i < n; i += 64) {
+      const uint32_t src = i < 64 ? src0 : idx[b0 + i];
       HgHit h = hits[src];
       h.to &= ~HG_HIT_SINGLE_BIT;
+      h.line_no &= (1ull << HG_HIT_REL_SHIFT) - 1ull;
       oh[k0 + i] = h;
       oa[k0 + i] = aux[src];
     }
