@@ -171,6 +171,7 @@ class HgScanner {
   // chunked pipeline: the stream pass of chunk c+1 overlaps the verify / confirm passes of chunk c
   static constexpr int kMaxChunks = 64;
   hipStream_t side_stream_ = nullptr;
+  hipEvent_t ev_tile_done_ = nullptr;  // the last chunk's tile scan is done (the early finalize starts behind it)
   hipEvent_t ev_fin_early_ = nullptr;  // the finalize of the earlier chunks' buckets (beside the last chunk's side passes) is done
   hipEvent_t ev_k1_begin_[kMaxChunks] = {}, ev_k1_end_[kMaxChunks] = {}, ev_side_done_[kMaxChunks] = {};
   // bucketed emission + finalize (hg_fin_*): records per bucket / kept counts -> output positions / {kept, raw} totals;

@@ -31,10 +31,10 @@ __global__ void hg_block_scan_kernel(HgConfirmArgs a, const uint32_t *pattern_fl
 __global__ void hg_reset_kernel(uint32_t *state, uint32_t state_words, HgTileBase *final_state, uint64_t line_base, uint32_t *fill, uint32_t nb, uint32_t *defer_count,
                                 uint32_t ndefer);
 __global__ void hg_fin_sort_small_kernel(const HgHit *hits, uint32_t *idx, const uint32_t *fill, uint32_t b_lo, uint32_t b_hi, uint32_t cap, uint32_t id_bits,
-                                         uint32_t to_bits, uint32_t *kept_count, uint32_t *raw_total, uint32_t *big_list, uint32_t *big_count);
+                                         uint32_t to_bits, uint32_t *kept_count, uint32_t *big_list, uint32_t *big_count);
 __global__ void hg_fin_sort_big_kernel(const HgHit *hits, uint32_t *idx, const uint32_t *fill, const uint32_t *big_list, const uint32_t *big_count, uint32_t cap,
-                                       uint32_t id_bits, uint32_t to_bits, uint32_t *kept_count, uint32_t *raw_total, uint32_t *overflow);
-__global__ void hg_fin_scan_kernel(uint32_t *kept_count, uint32_t b_lo, uint32_t b_hi, uint32_t *total);
+                                       uint32_t id_bits, uint32_t to_bits, uint32_t *kept_count, uint32_t *overflow);
+__global__ void hg_fin_scan_kernel(uint32_t *kept_count, uint32_t b_lo, uint32_t b_hi, uint32_t *total, const uint32_t *fill, uint32_t cap);
 __global__ void hg_fin_gather_kernel(const HgHit *hits, const HgHitAux *aux, const uint32_t *idx, const uint32_t *kept_base, const uint32_t *total, uint32_t b_lo,
                                      uint32_t b_hi, uint32_t cap, HgHit *oh, HgHitAux *oa);
 __global__ void hg_key_kernel(const HgHit *hits, const HgHitAux *aux, const HgPattern *patterns, uint32_t n, uint64_t *key, uint32_t *idx);
@@ -138,6 +138,7 @@ int HgScanner::create(std::shared_ptr<const HgDb> db, int device, HgScanner **ou
   for (auto &ev : s->ev_) HG_TRY(hipEventCreate(&ev), "hipEventCreate");
   HG_TRY(hipStreamCreateWithFlags(&s->side_stream_, hipStreamNonBlocking), "hipStreamCreate");
   HG_TRY(hipEventCreateWithFlags(&s->ev_fin_early_, hipEventDisableTiming), "hipEventCreate");
+  HG_TRY(hipEventCreateWithFlags(&s->ev_tile_done_, hipEventDisableTiming), "hipEventCreate");
 
   HG_TRY(hgmem::dev_alloc(&s->d_fin_fill_, HG_FIN_MAX_BUCKETS * 4, "d_fin_fill_"), "alloc finalize buckets");
   HG_TRY(hgmem::dev_alloc(&s->d_fin_kept_, HG_FIN_MAX_BUCKETS * 4, "d_fin_kept_"), "alloc finalize buckets");
@@ -165,6 +166,7 @@ HgScanner::~HgScanner() {
   }
   if (side_stream_) (void)hipStreamDestroy(side_stream_);
   if (ev_fin_early_) (void)hipEventDestroy(ev_fin_early_);
+  if (ev_tile_done_) (void)hipEventDestroy(ev_tile_done_);
 
   hgmem::dev_free(d_fin_fill_, "d_fin_fill_");
   hgmem::dev_free(d_fin_kept_, "d_fin_kept_");
@@ -354,10 +356,10 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       const uint32_t nbk = hi - lo, cu = static_cast<uint32_t>(num_cus_);
       HG_TRY(hipMemsetAsync(d_fin_total_ + 2, 0, 4, s), "memset work list");  // (large buckets of this range)
       hipLaunchKernelGGL(hg_fin_sort_small_kernel, dim3(std::min<uint32_t>((nbk + 3) / 4, cu * 8)), dim3(256), 0, s, d_hits_raw_, d_perm_a_, d_fin_fill_, lo, hi, fin_cap, id_bits, to_bits,
-                         d_fin_kept_, d_fin_total_ + 1, d_fin_big_, d_fin_total_ + 2);
+                         d_fin_kept_, d_fin_big_, d_fin_total_ + 2);
       hipLaunchKernelGGL(hg_fin_sort_big_kernel, dim3(std::min<uint32_t>(nbk, cu * 3)), dim3(256), 0, s, d_hits_raw_, d_perm_a_, d_fin_fill_, d_fin_big_, d_fin_total_ + 2, fin_cap, id_bits,
-                         to_bits, d_fin_kept_, d_fin_total_ + 1, d_selected_ + 1);
-      hipLaunchKernelGGL(hg_fin_scan_kernel, dim3(1), dim3(1024), 0, s, d_fin_kept_, lo, hi, d_fin_total_);
+                         to_bits, d_fin_kept_, d_selected_ + 1);
+      hipLaunchKernelGGL(hg_fin_scan_kernel, dim3(1), dim3(1024), 0, s, d_fin_kept_, lo, hi, d_fin_total_, d_fin_fill_, fin_cap);
       hipLaunchKernelGGL(hg_fin_gather_kernel, dim3(std::min<uint32_t>((nbk + 3) / 4, cu * 8)), dim3(256), 0, s, d_hits_raw_, d_aux_raw_, d_perm_a_, d_fin_kept_, d_fin_total_, lo, hi, fin_cap,
                          d_hits_out_, d_aux_out_);
       HG_TRY(hipGetLastError(), "finalize launch");
@@ -404,21 +406,6 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       HG_TRY(hipGetLastError(), "hg_stream_kernel launch");
       HG_TRY(hipEventRecord(piped ? ev_k1_end_[c] : ev_[2], stream), "event");
       if (piped) HG_TRY(hipStreamWaitEvent(side, ev_k1_end_[c], 0), "stream wait");
-      if (piped && bucketed && c + 1 == nchunks && c >= 1 && !std::getenv("HG_NO_EARLY_FINALIZE")) {
-        // The last stream launch is queued.  Behind it, on this stream, the buckets that the earlier chunks have completed
-        // are finalized WHILE the side stream works through the last chunk's verify / confirm passes (both have the chip to
-        // themselves by then); only the last chunk's buckets remain for after those.  (Finalizing a chunk's buckets beside
-        // the NEXT chunk's stream pass was tried: it slowed the stream pass by more than it saved.)
-        const uint64_t prev_end = std::min<uint64_t>(t0 << HG_TILE_SHIFT, nbytes);  // a later hit's line starts less than bs1 bytes before it
-        const uint32_t lim = static_cast<uint32_t>(std::min<uint64_t>((prev_end > bs1 ? prev_end - bs1 : 0) >> fin_shift, fin_nb));
-        if (lim > fin_done) {
-          HG_TRY(hipStreamWaitEvent(stream, ev_side_done_[c - 1], 0), "stream wait");  // the earlier chunks' hits are all in their buckets
-          if (int rc = launch_fin(stream, fin_done, lim)) return rc;
-          HG_TRY(hipEventRecord(ev_fin_early_, stream), "event");
-          fin_done = lim;
-          fin_early = true;
-        }
-      }
 
       HgConfirmArgs ca{};
       ca.text = text;
@@ -460,6 +447,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
         hipLaunchKernelGGL(hg_tile_spine_kernel, dim3(1), dim3(256), 0, side, d_agg_, nblocks, bs1, d_block_base_, d_final_);
         hipLaunchKernelGGL(hg_tile_apply_kernel, dim3(nblocks), dim3(256), 0, side, d_sums_, t0, t1, bs1, d_block_base_, d_bases_);
         HG_TRY(hipGetLastError(), "tile scan launch");
+        if (piped && c + 1 == nchunks) HG_TRY(hipEventRecord(ev_tile_done_, side), "event");  // (the early finalize starts behind the tile scan)
         if (has_anchored) {
           const uint32_t verify_blocks = segs_c * HG_CONFIRM_SPLIT;  // HG_CONFIRM_SPLIT blocks share candidate segment b
           uint32_t fast_modes = 0, mode_mask = 0xF;
@@ -500,6 +488,22 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
           }
           if (nall > nfast) hipLaunchKernelGGL(hg_always_on_kernel, dim3(always_blocks), dim3(256), 0, side, ca, nfast, nall);
           HG_TRY(hipGetLastError(), "hg_always_on_kernel launch");
+        }
+      }
+      if (piped && bucketed && c + 1 == nchunks && c >= 1 && !std::getenv("HG_NO_EARLY_FINALIZE")) {
+        // The last stream launch is queued.  Behind it, on this stream, the buckets that the earlier chunks have completed
+        // are finalized WHILE the side stream works through the last chunk's verify / confirm passes (both have the chip to
+        // themselves by then); only the last chunk's buckets remain for after those.  (Finalizing a chunk's buckets beside
+        // the NEXT chunk's stream pass was tried: it slowed the stream pass by more than it saved.)
+        const uint64_t prev_end = std::min<uint64_t>(t0 << HG_TILE_SHIFT, nbytes);  // a later hit's line starts less than bs1 bytes before it
+        const uint32_t lim = static_cast<uint32_t>(std::min<uint64_t>((prev_end > bs1 ? prev_end - bs1 : 0) >> fin_shift, fin_nb));
+        if (lim > fin_done) {
+          HG_TRY(hipStreamWaitEvent(stream, ev_side_done_[c - 1], 0), "stream wait");  // the earlier chunks' hits are all in their buckets
+          HG_TRY(hipStreamWaitEvent(stream, ev_tile_done_, 0), "stream wait");        // ... and the last chunk's tile scan (a one-block latency chain) is through
+          if (int rc = launch_fin(stream, fin_done, lim)) return rc;
+          HG_TRY(hipEventRecord(ev_fin_early_, stream), "event");
+          fin_done = lim;
+          fin_early = true;
         }
       }
       if (bucketed && c + 1 == nchunks) {  // the side passes of the last chunk are queued: order what is left

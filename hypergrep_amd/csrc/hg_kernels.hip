@@ -1766,11 +1766,9 @@ __device__ __forceinline__ uint64_t fin_key(const HgHit &h, uint32_t id_bits, ui
 // SINGLEMATCH report (bit 0) is kept only if it is the first one of its (line, id) = key >> group_shift.
 // Buckets of up to 64 reports (nearly all of them): one wave, one report per lane, the rules as bit operations on ballots.
 __global__ __launch_bounds__(256) void hg_fin_sort_small_kernel(const HgHit *hits, uint32_t *idx, const uint32_t *fill, uint32_t b_lo, uint32_t b_hi, uint32_t cap,
-                                                                uint32_t id_bits, uint32_t to_bits, uint32_t *kept_count, uint32_t *raw_total, uint32_t *big_list,
-                                                                uint32_t *big_count) {
+                                                                uint32_t id_bits, uint32_t to_bits, uint32_t *kept_count, uint32_t *big_list, uint32_t *big_count) {
   const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = (gridDim.x * blockDim.x) >> 6;
   const uint32_t group_shift = to_bits + 1;
-  uint32_t seen = 0;
   // A bucket's fill level and its first 64 records are loaded TOGETHER (lanes past the fill level read records of the same
   // region that are simply not used), and one bucket ahead: the loads of bucket b + waves are in flight while bucket b is
   // ordered.  Per bucket the wave then pays the sorting network, not two memory round trips.
@@ -1793,7 +1791,6 @@ __global__ __launch_bounds__(256) void hg_fin_sort_small_kernel(const HgHit *hit
       if (lane == 0) kept_count[b] = 0;
       continue;
     }
-    seen += n;
     const uint32_t b0 = b * cap;
     uint64_t k = lane < n ? fin_key(h, id_bits, to_bits) : ~0ull;  // (padding sorts last; a real key never has all bits set)
     uint32_t x = b0 + lane;
@@ -1828,11 +1825,10 @@ __global__ __launch_bounds__(256) void hg_fin_sort_small_kernel(const HgHit *hit
     if (keep) idx[b0 + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(km >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(km), 0u))] = x;
     if (lane == 0) kept_count[b] = static_cast<uint32_t>(__popcll(km));
   }
-  if (lane == 0 && seen) atomicAdd(raw_total, seen);
 }
 // Larger buckets (hits clustered on few lines): one block sorts the bucket in LDS.
 __global__ __launch_bounds__(256) void hg_fin_sort_big_kernel(const HgHit *hits, uint32_t *idx, const uint32_t *fill, const uint32_t *big_list, const uint32_t *big_count,
-                                                              uint32_t cap, uint32_t id_bits, uint32_t to_bits, uint32_t *kept_count, uint32_t *raw_total, uint32_t *overflow) {
+                                                              uint32_t cap, uint32_t id_bits, uint32_t to_bits, uint32_t *kept_count, uint32_t *overflow) {
   __shared__ uint64_t s_key[HG_FIN_BUCKET_CAP];
   __shared__ uint32_t s_idx[HG_FIN_BUCKET_CAP];
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -1856,7 +1852,6 @@ __global__ __launch_bounds__(256) void hg_fin_sort_big_kernel(const HgHit *hits,
       s_key[i] = i < n ? fin_key(hits[b0 + i], id_bits, to_bits) : ~0ull;
       s_idx[i] = b0 + i;
     }
-    if (tid == 0) atomicAdd(raw_total, n);
     __syncthreads();
     for (uint32_t k = 2; k <= p2; k <<= 1)
       for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -1906,26 +1901,37 @@ __global__ __launch_bounds__(256) void hg_fin_sort_big_kernel(const HgHit *hits,
 // One block: kept_count[b_lo, b_hi) -> exclusive positions in the compact output, continuing from *total (the kept records of
 // the bucket ranges finalized before); *total moves on.
 constexpr uint32_t HG_FIN_SCAN_THREADS = 1024;
-__global__ __launch_bounds__(HG_FIN_SCAN_THREADS) void hg_fin_scan_kernel(uint32_t *kept_count, uint32_t b_lo, uint32_t b_hi, uint32_t *total) {
-  __shared__ uint32_t s_wave[HG_FIN_SCAN_THREADS / 64];
+__global__ __launch_bounds__(HG_FIN_SCAN_THREADS) void hg_fin_scan_kernel(uint32_t *kept_count, uint32_t b_lo, uint32_t b_hi, uint32_t *total, const uint32_t *fill,
+                                                                          uint32_t cap) {
+  // total[0] += kept records of the range, total[1] += raw records of the range (fill levels, a bucket holds at most cap)
+  __shared__ uint32_t s_wave[HG_FIN_SCAN_THREADS / 64], s_raw[HG_FIN_SCAN_THREADS / 64];
   constexpr uint32_t WAVES = HG_FIN_SCAN_THREADS / 64;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t carry = *total;
   // wave w owns a contiguous share of the range and walks it 64 entries at a time (coalesced): first the share's sum ...
   const uint32_t share = ((b_hi - b_lo + WAVES - 1) / WAVES + 63u) & ~63u;
   const uint32_t w_lo = b_lo + wave * share, w_hi = w_lo + share < b_hi ? w_lo + share : b_hi;
-  uint32_t sum = 0;
+  uint32_t sum = 0, raw = 0;
 #pragma unroll 8
-  for (uint32_t i = w_lo + lane; i < w_hi; i += 64) sum += kept_count[i];
+  for (uint32_t i = w_lo + lane; i < w_hi; i += 64) {
+    sum += kept_count[i];
+    const uint32_t f = fill[i];
+    raw += f < cap ? f : cap;
+  }
   sum = wave_inclusive_scan(sum, lane);
-  if (lane == 63) s_wave[wave] = sum;
+  raw = wave_inclusive_scan(raw, lane);
+  if (lane == 63) {
+    s_wave[wave] = sum;
+    s_raw[wave] = raw;
+  }
   __syncthreads();  // (also: everyone has read *total before thread 0 rewrites it)
-  uint32_t run = carry, all = 0;
+  uint32_t run = carry, all = 0, all_raw = 0;
 #pragma unroll
   for (uint32_t w = 0; w < WAVES; w++) {
     const uint32_t t = s_wave[w];
     run += w < wave ? t : 0u;
     all += t;
+    all_raw += s_raw[w];
   }
   // ... then the exclusive positions (the entries come from the cache this time)
   for (uint32_t i0 = w_lo; i0 < w_hi; i0 += 64) {
@@ -1935,7 +1941,10 @@ __global__ __launch_bounds__(HG_FIN_SCAN_THREADS) void hg_fin_scan_kernel(uint32
     if (i < w_hi) kept_count[i] = run + incl - c;
     run += __builtin_amdgcn_readlane(incl, 63);
   }
-  if (threadIdx.x == 0) *total = carry + all;
+  if (threadIdx.x == 0) {
+    total[0] = carry + all;
+    total[1] += all_raw;
+  }
 }
 // kept records of bucket b (idx[b * cap ...] in final order) -> out[kept_base[b] ...]; bucket b + 1's base (or *total for the
 // last bucket of the range) ends the run.  One wave per bucket, grid-stride.
