@@ -1174,7 +1174,13 @@ __device__ __forceinline__ void confirm_tables_body(const HgConfirmArgs &a, uint
 // passes cost three latency tails, side by side one): blocks [k * blocks_per_mode, (k+1) * blocks_per_mode) work on the
 // k-th mode present in the database.
 __global__ __launch_bounds__(HG_CONFIRM_THREADS) void hg_confirm_fast_kernel(HgConfirmArgs a, uint32_t blocks_per_mode) {
-  const uint32_t k = blockIdx.x / blocks_per_mode, vblock = blockIdx.x % blocks_per_mode;  // block-uniform
+  // blocks of the modes alternate in launch order (block b works for the (b mod #modes)-th mode present, slowest routine
+  // first): every mode progresses from the first round of blocks on, instead of the automaton modes — few items, long
+  // chains — starting when the literal-only blocks are through
+  uint32_t nmodes = 0;
+  for (uint32_t m = 0; m < 3; m++) nmodes += a.mode_present[m] ? 1u : 0u;
+  if (nmodes == 0) return;
+  const uint32_t k = nmodes - 1u - blockIdx.x % nmodes, vblock = blockIdx.x / nmodes;  // block-uniform
   uint32_t mode = 0, seen = 0;
   for (uint32_t m = 0; m < 3; m++)
     if (a.mode_present[m] && seen++ == k) mode = m;
