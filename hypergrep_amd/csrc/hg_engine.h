@@ -29,7 +29,8 @@ struct HgDeferred {
 // The scanner's small device state is ONE block of words (reset by one launch, read back by one copy):
 //   [0, 8) counters, [8, 24) tile cursors, [24, 28) finalize totals {kept, raw, large buckets, -}, [28, 30) {count, overflow flag}
 //   of the finalize, [32, 36) tile-scan state (HgTileBase)
-enum { HG_ST_FIN_TOTAL = 24, HG_ST_SELECTED = 28, HG_ST_FINAL = 32, HG_ST_WORDS = 36, HG_ST_ZERO_WORDS = 32 };
+enum { HG_ST_FIN_TOTAL = 24, HG_ST_SELECTED = 28, HG_ST_FINAL = 32, HG_ST_WORDS = 36, HG_ST_ZERO_WORDS = 32,
+       HG_ST_BLOCK_DONE = 40 };  // (outside the words a pass resets: workgroups of hg_block_small_kernel that have finished)
 enum { HG_CNT_CANDS = 0, HG_CNT_HITS = 1, HG_CNT_CAND_NEED = 2, HG_CNT_HIT_NEED = 3, HG_CNT_DEFER_NEED = 4, HG_CNT_WORDS = 8,
        HG_CNT_CURSOR0 = 8,      // one tile cursor per pipeline chunk follows the counters proper
        HG_CNT_ALL_WORDS = 8 + 16 };
@@ -94,6 +95,8 @@ struct HgConfirmArgs {
   uint32_t *bucket_fill;
   uint32_t *counters;
 };
+constexpr uint32_t HG_BLOCK_SMALL_MAX = 8192;   // Face A: blocks up to this many bytes take the one-launch path (hg_block_small_kernel)
+constexpr uint32_t HG_BLOCK_SMALL_SEG = 1024;   // ... reports per workgroup (256 expressions) it can hold
 constexpr uint32_t HG_HIT_REL_SHIFT = 40;  // raw bucketed records: line_no (< 2^40) | line start inside the bucket (< 2^24) << 40
 constexpr uint32_t HG_HIT_SINGLE_BIT = 0x80000000u;  // raw bucketed records: bit 31 of `to` = the expression has HS_FLAG_SINGLEMATCH (`to` < 2^31)
 
@@ -120,6 +123,12 @@ class HgScanner {
   int scan(const void *d_text, uint64_t nbytes, int buffer_size, uint64_t line_base, hipStream_t stream, HgScanOutput *out);
   // Block mode (hs_scan): the whole buffer is one scan unit; hits carry line_no 0 and `to` relative to the buffer start.
   int scan_block(const void *d_text, uint64_t nbytes, hipStream_t stream, HgScanOutput *out);
+  // Block mode for short blocks held in PINNED host memory (readable up to nbytes rounded up to 16): one launch, raw
+  // reports {0, id, to | HG_HIT_SINGLE_BIT} in h_out (a segment of HG_BLOCK_SMALL_SEG records per 256 expressions), their
+  // number per segment in h_counts; the caller synchronises the stream and applies the report rules.  Returns the number
+  // of segments, 0 if the block or the pattern set is too large for this path.
+  // *h_flag (pinned) receives `seq` when every segment is written: the caller may poll it instead of synchronising.
+  uint32_t launch_block_small(const uint8_t *h_text, uint32_t nbytes, hipStream_t stream, HgHit *h_out, uint32_t *h_counts, uint32_t *h_flag, uint32_t seq);
   const std::string &last_error() const { return err_; }
   int device() const { return device_; }
 

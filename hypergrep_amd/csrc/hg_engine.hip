@@ -28,6 +28,8 @@ __global__ void hg_always_on_fast_kernel(HgConfirmArgs a);
 __global__ void hg_always_on_finish_kernel(HgConfirmArgs a);
 __global__ void hg_block_mark_kernel(HgConfirmArgs a, uint32_t *pattern_flags);
 __global__ void hg_block_scan_kernel(HgConfirmArgs a, const uint32_t *pattern_flags);
+__global__ void hg_block_small_kernel(HgDbView db, const uint8_t *h_text, uint32_t length, HgHit *h_out, uint32_t seg_cap, uint32_t *h_counts, uint32_t *d_done,
+                                      uint32_t *h_flag, uint32_t seq);
 __global__ void hg_reset_kernel(uint32_t *state, uint32_t state_words, HgTileBase *final_state, uint64_t line_base, uint32_t *fill, uint32_t nb, uint32_t *defer_count,
                                 uint32_t ndefer);
 __global__ void hg_fin_sort_small_kernel(const HgHit *hits, uint32_t *idx, const uint32_t *fill, uint32_t b_lo, uint32_t b_hi, uint32_t cap, uint32_t id_bits,
@@ -129,6 +131,7 @@ int HgScanner::create(std::shared_ptr<const HgDb> db, int device, HgScanner **ou
   s->view_.fold_mask = db->fold_mask;
   s->view_.window_mask = db->window_mask;
   HG_TRY(hgmem::dev_alloc(&s->d_counters_, 64 * 4, "d_state_"), "alloc state");  // the state block (hg_engine.h, HG_ST_*)
+  HG_TRY(hipMemset(s->d_counters_, 0, 64 * 4), "clear state");
   s->d_fin_total_ = s->d_counters_ + HG_ST_FIN_TOTAL;
   s->d_selected_ = s->d_counters_ + HG_ST_SELECTED;
   s->d_final_ = reinterpret_cast<HgTileBase *>(s->d_counters_ + HG_ST_FINAL);
@@ -645,6 +648,15 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   (void)hipEventElapsedTime(&out->ms_total, ev_[0], ev_[3]);
 #undef HG_TRY
   return HG_OK;
+}
+
+uint32_t HgScanner::launch_block_small(const uint8_t *h_text, uint32_t nbytes, hipStream_t stream, HgHit *h_out, uint32_t *h_counts, uint32_t *h_flag, uint32_t seq) {
+  const uint32_t segs = (view_.npatterns + 255u) / 256u;
+  if (nbytes == 0 || nbytes > HG_BLOCK_SMALL_MAX || segs > 64) return 0;
+  if (hipSetDevice(device_) != hipSuccess) return 0;
+  hipLaunchKernelGGL(hg_block_small_kernel, dim3(segs), dim3(256), 0, stream, view_, h_text, nbytes, h_out, static_cast<uint32_t>(HG_BLOCK_SMALL_SEG), h_counts,
+                     d_counters_ + HG_ST_BLOCK_DONE, h_flag, seq);
+  return hipGetLastError() == hipSuccess ? segs : 0;
 }
 
 int HgScanner::scan_block(const void *d_text, uint64_t nbytes, hipStream_t stream, HgScanOutput *out) {

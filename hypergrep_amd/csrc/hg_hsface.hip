@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -28,6 +29,11 @@ struct hs_scratch {
   uint8_t *d_text = nullptr;
   size_t d_cap = 0;
   std::vector<HgHit> hits;
+  // short blocks (HgScanner::launch_block_small): pinned copies of the block and of the raw reports
+  uint8_t *h_text = nullptr;
+  HgHit *h_out = nullptr;
+  uint32_t *h_counts = nullptr;  // [0, 64) reports per segment, [64] completion flag
+  uint32_t seq = 0;
 };
 
 extern "C" {
@@ -81,6 +87,11 @@ int hs_alloc_scratch(const hs_database_t *db, hs_scratch_t **scratch) {
     return HS_NOMEM;
   }
   if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return HS_NOMEM;
+  if (hgmem::host_alloc(&s->h_text, HG_BLOCK_SMALL_MAX + 16, "hs h_text") != hipSuccess ||
+      hgmem::host_alloc(&s->h_out, 64 * HG_BLOCK_SMALL_SEG * sizeof(HgHit), "hs h_out") != hipSuccess ||
+      hgmem::host_alloc(&s->h_counts, 80 * sizeof(uint32_t), "hs h_counts") != hipSuccess)
+    return HS_NOMEM;
+  s->h_counts[64] = 0;
   *scratch = s.release();
   return HS_SUCCESS;
 }
@@ -90,6 +101,9 @@ int hs_free_scratch(hs_scratch_t *scratch) {
   if (scratch->sc) (void)hipSetDevice(scratch->sc->device());
   delete scratch->sc;
   hgmem::dev_free(scratch->d_text, "hs d_text");
+  hgmem::host_free(scratch->h_text, "hs h_text");
+  hgmem::host_free(scratch->h_out, "hs h_out");
+  hgmem::host_free(scratch->h_counts, "hs h_counts");
   if (scratch->stream) (void)hipStreamDestroy(scratch->stream);
   delete scratch;
   return HS_SUCCESS;
@@ -101,6 +115,61 @@ int hs_scan(const hs_database_t *db, const char *data, unsigned int length, unsi
   if (!db || !scratch || !scratch->sc || scratch->db != db->db || (!data && length)) return HS_INVALID;
   if (length == 0) return HS_SUCCESS;  // no expression can match the empty buffer (such expressions are rejected at compile time)
   if (hipSetDevice(scratch->sc->device()) != hipSuccess) return HS_INVALID;
+  // Short blocks (the reference shim scans line by line, hyperscanner.c:217): one launch on a pinned copy of the block,
+  // raw reports straight into pinned memory, the report rules on the host.
+  if (length <= HG_BLOCK_SMALL_MAX && !std::getenv("HG_NO_BLOCK_SMALL")) {
+    std::memcpy(scratch->h_text, data, length);
+    std::memset(scratch->h_text + length, 0, (16 - (length & 15)) & 15);
+    const uint32_t seq = ++scratch->seq ? scratch->seq : ++scratch->seq;  // (never 0)
+    const uint32_t segs = scratch->sc->launch_block_small(scratch->h_text, length, scratch->stream, scratch->h_out, scratch->h_counts, scratch->h_counts + 64, seq);
+    if (segs) {
+      // wait for the kernel's completion word in pinned memory (a few microseconds of polling; a stream synchronisation
+      // sleeps until an interrupt); after ~2 ms of polling fall back to the synchronisation, which also reports errors
+      volatile uint32_t *flag = scratch->h_counts + 64;
+      bool done = false;
+      for (uint32_t spin = 0; spin < 400000 && !(done = *flag == seq); spin++) __builtin_ia32_pause();
+      if (!done && hipStreamSynchronize(scratch->stream) != hipSuccess) return HS_INVALID;
+      std::atomic_thread_fence(std::memory_order_acquire);
+      bool fits = true;
+      scratch->hits.clear();
+      for (uint32_t g = 0; g < segs && fits; g++) {
+        const uint32_t n = scratch->h_counts[g];
+        fits = n <= HG_BLOCK_SMALL_SEG;
+        if (fits) scratch->hits.insert(scratch->hits.end(), scratch->h_out + static_cast<size_t>(g) * HG_BLOCK_SMALL_SEG, scratch->h_out + static_cast<size_t>(g) * HG_BLOCK_SMALL_SEG + n);
+      }
+      if (fits) {
+        // report rules per id (hg_post.h, restated on the raw records): SINGLEMATCH expressions sharing an id give one
+        // report (the smallest end offset), the others every distinct end offset, identical (id, to) once
+        auto &h = scratch->hits;
+        auto to_of = [](const HgHit &x) { return x.to & ~HG_HIT_SINGLE_BIT; };
+        auto single_of = [](const HgHit &x) { return (x.to & HG_HIT_SINGLE_BIT) != 0; };
+        std::sort(h.begin(), h.end(), [&](const HgHit &a, const HgHit &b) {
+          if (a.id != b.id) return a.id < b.id;
+          if (to_of(a) != to_of(b)) return to_of(a) < to_of(b);
+          return single_of(a) < single_of(b);
+        });
+        size_t kept = 0;
+        bool seen_single = false;
+        for (size_t i = 0; i < h.size(); i++) {
+          if (i == 0 || h[i].id != h[i - 1].id) seen_single = false;
+          const bool dup = i > 0 && h[i].id == h[i - 1].id && to_of(h[i]) == to_of(h[i - 1]);
+          const bool single = single_of(h[i]);
+          const bool keep = !dup && !(single && seen_single);
+          if (single) seen_single = true;
+          if (keep) {
+            HgHit out = h[i];
+            out.to = to_of(h[i]);
+            h[kept++] = out;
+          }
+        }
+        h.resize(kept);
+        std::sort(h.begin(), h.end(), [](const HgHit &a, const HgHit &b) { return a.to != b.to ? a.to < b.to : a.id < b.id; });
+        for (const HgHit &x : h)
+          if (on_event && on_event(x.id, 0, x.to, 0, context)) return HS_SCAN_TERMINATED;
+        return HS_SUCCESS;
+      }
+    }
+  }
   if (scratch->d_cap < length) {
     hgmem::dev_free(scratch->d_text, "hs d_text");
     scratch->d_text = nullptr;

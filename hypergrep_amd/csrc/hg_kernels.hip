@@ -1738,6 +1738,46 @@ __global__ __launch_bounds__(256) void hg_block_scan_kernel(HgConfirmArgs a, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// Block mode, short blocks (Face A on a line of text): ONE launch and no device-side bookkeeping.  The block's bytes sit in
+// pinned host memory (the caller's copy of hs_scan's `data`); every workgroup stages them in LDS with coalesced 16-byte
+// loads (one trip over the host link), then each lane runs ONE expression's automaton over the LDS copy (hg_nfa_scan, the
+// reference routine) and writes its reports to the workgroup's segment of a pinned result array; the host applies the
+// report rules (a handful of records).  Replaces copy + reset + stream + mark + scan + finalize + two copies for blocks of
+// up to HG_BLOCK_SMALL_MAX bytes.
+// Completion is signalled through pinned memory too: the last workgroup to finish writes the call's sequence number to
+// *h_flag behind a system-scope fence, and the caller polls that word instead of sleeping in a stream synchronisation
+// (an interrupt-driven wake-up costs more than the kernel).
+__global__ __launch_bounds__(256) void hg_block_small_kernel(HgDbView db, const uint8_t *h_text, uint32_t length, HgHit *h_out, uint32_t seg_cap, uint32_t *h_counts,
+                                                             uint32_t *d_done, uint32_t *h_flag, uint32_t seq) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_text[HG_BLOCK_SMALL_MAX + 16];
+  __shared__ uint32_t s_n;
+  if (threadIdx.x == 0) s_n = 0;
+  const uint32_t chunks = (length + 15u) >> 4;  // (the pinned buffer is readable up to its size rounded up to 16)
+  for (uint32_t i = threadIdx.x; i < chunks; i += blockDim.x) reinterpret_cast<uint4 *>(s_text)[i] = reinterpret_cast<const uint4 *>(h_text)[i];
+  __syncthreads();
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < db.npatterns) {
+    const HgPattern &pat = db.patterns[p];
+    const uint32_t single = pat.single ? HG_HIT_SINGLE_BIT : 0u;
+    HgHit *seg = h_out + static_cast<uint64_t>(blockIdx.x) * seg_cap;
+    hg_nfa_scan(db.pool, pat, s_text, length, [&](uint32_t to) {
+      const uint32_t slot = atomicAdd(&s_n, 1u);
+      if (slot < seg_cap) seg[slot] = HgHit{0, pat.id, to | single};
+    });
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    h_counts[blockIdx.x] = s_n;  // (more than seg_cap: the caller takes the general path)
+    __threadfence_system();       // this workgroup's reports and count are visible to the host ...
+    if (atomicAdd(d_done, 1u) == gridDim.x - 1) {  // ... and it was the last one
+      *d_done = 0;
+      __threadfence_system();
+      __hip_atomic_store(h_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // One launch puts the scanner's device state in place for a pass (it used to be half a dozen memsets and a host-to-device
 // copy, each a launch of its own in front of the first stream kernel): counters, tile cursors, finalize totals and flags
 // zeroed, the tile-scan state set to (carry-in line start 0, first line number), bucket fill levels and the
