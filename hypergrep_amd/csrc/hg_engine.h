@@ -95,8 +95,11 @@ struct HgConfirmArgs {
   uint32_t *bucket_fill;
   uint32_t *counters;
 };
+constexpr uint32_t HG_BLOCK_SMALL_POOL = 10240;  // ... words of automaton tables a workgroup of that path stages in LDS (40 KiB)
+constexpr uint32_t HG_BLOCK_SLICED_MAX = 2047;   // ... blocks up to this many bytes are split over the lanes by start position
+constexpr uint32_t HG_BLOCK_SLICED_WORDS = 64;   // ... (bitmap of emitted ends per expression: ends 0 .. HG_BLOCK_SLICED_MAX)
 constexpr uint32_t HG_BLOCK_SMALL_MAX = 8192;   // Face A: blocks up to this many bytes take the one-launch path (hg_block_small_kernel)
-constexpr uint32_t HG_BLOCK_SMALL_SEG = 1024;   // ... reports per workgroup (256 expressions) it can hold
+constexpr uint32_t HG_BLOCK_SMALL_SEG = 1024;   // ... reports per workgroup (32 or 256 expressions) it can hold
 constexpr uint32_t HG_HIT_REL_SHIFT = 40;  // raw bucketed records: line_no (< 2^40) | line start inside the bucket (< 2^24) << 40
 constexpr uint32_t HG_HIT_SINGLE_BIT = 0x80000000u;  // raw bucketed records: bit 31 of `to` = the expression has HS_FLAG_SINGLEMATCH (`to` < 2^31)
 
@@ -124,7 +127,7 @@ class HgScanner {
   // Block mode (hs_scan): the whole buffer is one scan unit; hits carry line_no 0 and `to` relative to the buffer start.
   int scan_block(const void *d_text, uint64_t nbytes, hipStream_t stream, HgScanOutput *out);
   // Block mode for short blocks held in PINNED host memory (readable up to nbytes rounded up to 16): one launch, raw
-  // reports {0, id, to | HG_HIT_SINGLE_BIT} in h_out (a segment of HG_BLOCK_SMALL_SEG records per 256 expressions), their
+  // reports {0, id, to | HG_HIT_SINGLE_BIT} in h_out (a segment of HG_BLOCK_SMALL_SEG records per workgroup), their
   // number per segment in h_counts; the caller synchronises the stream and applies the report rules.  Returns the number
   // of segments, 0 if the block or the pattern set is too large for this path.
   // *h_flag (pinned) receives `seq` when every segment is written: the caller may poll it instead of synchronising.

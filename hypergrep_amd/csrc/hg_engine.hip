@@ -29,7 +29,7 @@ __global__ void hg_always_on_finish_kernel(HgConfirmArgs a);
 __global__ void hg_block_mark_kernel(HgConfirmArgs a, uint32_t *pattern_flags);
 __global__ void hg_block_scan_kernel(HgConfirmArgs a, const uint32_t *pattern_flags);
 __global__ void hg_block_small_kernel(HgDbView db, const uint8_t *h_text, uint32_t length, HgHit *h_out, uint32_t seg_cap, uint32_t *h_counts, uint32_t *d_done,
-                                      uint32_t *h_flag, uint32_t seq);
+                                      uint32_t *h_flag, uint32_t seq, uint32_t ppw);
 __global__ void hg_reset_kernel(uint32_t *state, uint32_t state_words, HgTileBase *final_state, uint64_t line_base, uint32_t *fill, uint32_t nb, uint32_t *defer_count,
                                 uint32_t ndefer);
 __global__ void hg_fin_sort_small_kernel(const HgHit *hits, uint32_t *idx, const uint32_t *fill, uint32_t b_lo, uint32_t b_hi, uint32_t cap, uint32_t id_bits,
@@ -651,11 +651,13 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
 }
 
 uint32_t HgScanner::launch_block_small(const uint8_t *h_text, uint32_t nbytes, hipStream_t stream, HgHit *h_out, uint32_t *h_counts, uint32_t *h_flag, uint32_t seq) {
-  const uint32_t segs = (view_.npatterns + 255u) / 256u;
-  if (nbytes == 0 || nbytes > HG_BLOCK_SMALL_MAX || segs > 64) return 0;
+  // 32 expressions per workgroup while 64 segments hold the set (their tables then usually fit in LDS), else 256
+  const uint32_t ppw = view_.npatterns <= 32u * 64u ? 32u : 256u;
+  const uint32_t segs = (view_.npatterns + ppw - 1) / ppw;
+  if (nbytes == 0 || nbytes > HG_BLOCK_SMALL_MAX || segs == 0 || segs > 64) return 0;
   if (hipSetDevice(device_) != hipSuccess) return 0;
   hipLaunchKernelGGL(hg_block_small_kernel, dim3(segs), dim3(256), 0, stream, view_, h_text, nbytes, h_out, static_cast<uint32_t>(HG_BLOCK_SMALL_SEG), h_counts,
-                     d_counters_ + HG_ST_BLOCK_DONE, h_flag, seq);
+                     d_counters_ + HG_ST_BLOCK_DONE, h_flag, seq, ppw);
   return hipGetLastError() == hipSuccess ? segs : 0;
 }
 

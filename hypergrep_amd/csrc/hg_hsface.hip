@@ -117,7 +117,8 @@ int hs_scan(const hs_database_t *db, const char *data, unsigned int length, unsi
   if (hipSetDevice(scratch->sc->device()) != hipSuccess) return HS_INVALID;
   // Short blocks (the reference shim scans line by line, hyperscanner.c:217): one launch on a pinned copy of the block,
   // raw reports straight into pinned memory, the report rules on the host.
-  if (length <= HG_BLOCK_SMALL_MAX && !std::getenv("HG_NO_BLOCK_SMALL")) {
+  static const bool small_path = !std::getenv("HG_NO_BLOCK_SMALL");
+  if (length <= HG_BLOCK_SMALL_MAX && small_path) {
     std::memcpy(scratch->h_text, data, length);
     std::memset(scratch->h_text + length, 0, (16 - (length & 15)) & 15);
     const uint32_t seq = ++scratch->seq ? scratch->seq : ++scratch->seq;  // (never 0)

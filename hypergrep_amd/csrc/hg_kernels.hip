@@ -1747,23 +1747,120 @@ __global__ __launch_bounds__(256) void hg_block_scan_kernel(HgConfirmArgs a, con
 // Completion is signalled through pinned memory too: the last workgroup to finish writes the call's sequence number to
 // *h_flag behind a system-scope fence, and the caller polls that word instead of sleeping in a stream synchronisation
 // (an interrupt-driven wake-up costs more than the kernel).
+// The automaton tables of a workgroup's expressions (consecutive in the pool: hg_compile.cpp lays an expression's reach /
+// follow / init / amask / acc tables out back to back, expression after expression) are staged in LDS as well when they fit
+// (`ppw` expressions per workgroup, 32 for sets of up to 2048 expressions): the per-byte step then is a chain of LDS reads
+// instead of dependent global loads.
+// A lone wave on an otherwise idle chip runs at idle clocks, and the automaton is a serial chain per byte (34 us per 100
+// bytes with one lane per expression), so blocks of up to HG_BLOCK_SLICED_MAX bytes are also split over the lanes by START
+// position: the step S' = (init | follow(S)) & reach[c] & mask is linear in (init, S), so the match ends of a block are the
+// union over slices of the ends of matches that START in the slice.  Lane (expression, slice k) injects the start states only
+// at the slice's bytes and runs on past its end until no state is alive (a literal's partial match dies within a few bytes;
+// an expression with .* runs to the end of the block, as before).  The same end found from two slices is emitted once
+// (a bitmap of ends per expression in LDS).
+template <typename Emit>
+__device__ __forceinline__ void hg_nfa_scan_slice(const uint32_t *pool, const HgPattern &p, const uint8_t *data, uint32_t len, uint32_t from, uint32_t upto, Emit &&emit) {
+  const uint32_t nw = p.nw;
+  const uint32_t *reach = pool + p.reach_off, *follow = pool + p.follow_off, *init = pool + p.init_off;
+  const uint32_t *amask = pool + p.amask_off, *acc = pool + p.acc_off;
+  const bool single = p.single != 0;
+  uint32_t pc = from ? hg_prev_ctx(data[from - 1]) : HG_PC_START;
+  if (nw == 1) {
+    uint32_t S = 0;
+    const uint32_t init0 = init[0];
+    for (uint32_t i = from; i < len; i++) {
+      if (i >= upto && S == 0) return;  // no start left and nothing alive
+      const uint32_t c = data[i];
+      const uint32_t cc = c == '\n' ? (i + 1 == len ? HG_NC_NLFINAL : HG_NC_NL) : (hg_is_word(c) ? HG_NC_WORD : HG_NC_OTHER);
+      if (S & acc[pc * 5 + cc]) {
+        emit(i);
+        if (single) return;
+      }
+      uint32_t T = i < upto ? init0 : 0u;
+      for (uint32_t x = S; x; x &= x - 1) T |= follow[hg_ctz(x)];
+      S = T & reach[c] & amask[pc * 4 + cc];
+      pc = hg_prev_ctx(c);
+    }
+    if (S & acc[pc * 5 + HG_NC_END]) emit(len);
+    return;
+  }
+  uint32_t S[HG_MAX_W], T[HG_MAX_W];
+  for (uint32_t w = 0; w < nw; w++) S[w] = 0;
+  uint32_t alive = 0;
+  for (uint32_t i = from; i < len; i++) {
+    if (i >= upto && alive == 0) return;
+    const uint32_t c = data[i];
+    const uint32_t cc = c == '\n' ? (i + 1 == len ? HG_NC_NLFINAL : HG_NC_NL) : (hg_is_word(c) ? HG_NC_WORD : HG_NC_OTHER);
+    const uint32_t *a = acc + (pc * 5 + cc) * nw;
+    uint32_t any = 0;
+    for (uint32_t w = 0; w < nw; w++) any |= S[w] & a[w];
+    if (any) {
+      emit(i);
+      if (single) return;
+    }
+    for (uint32_t w = 0; w < nw; w++) T[w] = i < upto ? init[w] : 0u;
+    for (uint32_t w = 0; w < nw; w++)
+      for (uint32_t x = S[w]; x; x &= x - 1) {
+        const uint32_t *f = follow + (w * 32 + hg_ctz(x)) * nw;
+        for (uint32_t k = 0; k < nw; k++) T[k] |= f[k];
+      }
+    const uint32_t *r = reach + c * nw, *m = amask + (pc * 4 + cc) * nw;
+    alive = 0;
+    for (uint32_t w = 0; w < nw; w++) alive |= S[w] = T[w] & r[w] & m[w];
+    pc = hg_prev_ctx(c);
+  }
+  const uint32_t *a = acc + (pc * 5 + HG_NC_END) * nw;
+  uint32_t any = 0;
+  for (uint32_t w = 0; w < nw; w++) any |= S[w] & a[w];
+  if (any) emit(len);
+}
+
 __global__ __launch_bounds__(256) void hg_block_small_kernel(HgDbView db, const uint8_t *h_text, uint32_t length, HgHit *h_out, uint32_t seg_cap, uint32_t *h_counts,
-                                                             uint32_t *d_done, uint32_t *h_flag, uint32_t seq) {
+                                                             uint32_t *d_done, uint32_t *h_flag, uint32_t seq, uint32_t ppw) {
   __shared__ __attribute__((aligned(16))) uint8_t s_text[HG_BLOCK_SMALL_MAX + 16];
+  __shared__ __attribute__((aligned(16))) uint32_t s_pool[HG_BLOCK_SMALL_POOL];
+  __shared__ uint32_t s_seen[32 * HG_BLOCK_SLICED_WORDS];  // sliced mode: ends already emitted, per expression of the workgroup
   __shared__ uint32_t s_n;
   if (threadIdx.x == 0) s_n = 0;
   const uint32_t chunks = (length + 15u) >> 4;  // (the pinned buffer is readable up to its size rounded up to 16)
   for (uint32_t i = threadIdx.x; i < chunks; i += blockDim.x) reinterpret_cast<uint4 *>(s_text)[i] = reinterpret_cast<const uint4 *>(h_text)[i];
+  const uint32_t first = blockIdx.x * ppw, last = min(first + ppw, db.npatterns);  // (first < npatterns: the grid is sized so)
+  const uint32_t npat = last - first;
+  const HgPattern &pl = db.patterns[last - 1];
+  const uint32_t lo = db.patterns[first].reach_off, hi = pl.acc_off + 20u * pl.nw;
+  const bool staged = hi - lo <= HG_BLOCK_SMALL_POOL;  // (uniform)
+  if (staged)
+    for (uint32_t i = threadIdx.x; i < hi - lo; i += blockDim.x) s_pool[i] = db.pool[lo + i];
+  // slices of at least 8 start positions, as many as the lanes allow
+  const bool sliced = ppw <= 32 && length <= HG_BLOCK_SLICED_MAX;
+  uint32_t slice_len = length, nslices = 1;
+  if (sliced) {
+    const uint32_t most = blockDim.x / npat;
+    slice_len = max(8u, (length + most - 1) / most);
+    nslices = (length + slice_len - 1) / slice_len;
+    const uint32_t words = (length >> 5) + 1;  // ends 0 .. length
+    for (uint32_t i = threadIdx.x; i < npat * HG_BLOCK_SLICED_WORDS; i += blockDim.x)
+      if ((i & (HG_BLOCK_SLICED_WORDS - 1)) < words) s_seen[i] = 0;
+  }
   __syncthreads();
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < db.npatterns) {
-    const HgPattern &pat = db.patterns[p];
+  const uint32_t j = threadIdx.x % npat, k = threadIdx.x / npat;  // expression of the workgroup, slice
+  if (k < nslices) {
+    const HgPattern pat = db.patterns[first + j];
     const uint32_t single = pat.single ? HG_HIT_SINGLE_BIT : 0u;
     HgHit *seg = h_out + static_cast<uint64_t>(blockIdx.x) * seg_cap;
-    hg_nfa_scan(db.pool, pat, s_text, length, [&](uint32_t to) {
+    auto emit = [&](uint32_t to) {
+      if (sliced && (atomicOr(&s_seen[j * HG_BLOCK_SLICED_WORDS + (to >> 5)], 1u << (to & 31)) >> (to & 31) & 1)) return;
       const uint32_t slot = atomicAdd(&s_n, 1u);
       if (slot < seg_cap) seg[slot] = HgHit{0, pat.id, to | single};
-    });
+    };
+    const uint32_t from = k * slice_len, upto = min(from + slice_len, length);
+    if (staged) {
+      HgPattern q = pat;  // the same tables, relative to the LDS copy
+      q.reach_off -= lo, q.follow_off -= lo, q.init_off -= lo, q.amask_off -= lo, q.acc_off -= lo;
+      hg_nfa_scan_slice(s_pool, q, s_text, length, from, upto, emit);
+    } else {
+      hg_nfa_scan_slice(db.pool, pat, s_text, length, from, upto, emit);
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {

@@ -398,6 +398,41 @@ def test_face_a_hs_scan_matches_oracle(torch_cuda):
     product.hs_free_compile_error(bad)
 
 
+def test_face_a_short_block_regimes(torch_cuda):
+    """hs_scan has three regimes by block length: split over lanes by start position (<= 2047 bytes), one lane per
+    expression (<= 8192), the general pipeline above; and the short-block kernel stages the automaton tables in LDS only when
+    they fit (<= 2048 expressions, 32 per workgroup).  Lengths on both sides of each boundary, expressions whose state
+    never dies (.*), multi-word automata, SINGLEMATCH and all-matches expressions sharing ids, and a 2100-expression set."""
+    import ctypes
+    import random
+
+    from hypergrep_amd import utils
+
+    product = utils._get_hyperscanner_lib()
+    oracle = ctypes.CDLL(os.path.join(oracle_py.ORACLE_DIR, "_build", "libhs.so.5"))
+    rng = random.Random(77)
+    patterns = ["needle_in_haystack", "fo+bar[0-9]*", "a.c", "st.*us=2", "^\\S+ \\S+", "[a-z]{3,40}=[0-9]{2,30} [a-z]{10,60}x", "\\bGET\\b", "0$", "(?i)error.*timeout"]
+    flags = [14, 6, 6, 6, 14, 6, 10, 14, 6]
+    ids = [0, 1, 2, 2, 3, 4, 5, 6, 1]
+    filler = regex_gen.random_text(rng, 400, maxlen=120) + b"status=200 GET /a.c needle_in_haystack foobar12 ERROR x timeout\n"
+    blocks = []
+    for n in (1, 7, 8, 9, 63, 64, 65, 511, 2040, 2046, 2047, 2048, 2049, 4095, 8191, 8192, 8193, 20000):
+        at = rng.randrange(0, len(filler) - n) if n < len(filler) else 0
+        blocks.append(filler[at:at + n] if n < len(filler) else (filler * 2)[:n])
+        blocks.append(filler[-n:])  # ends with the dense line and its newline
+    got = _hs_events(product, patterns, flags, ids, blocks)
+    want = _hs_events(oracle, patterns, flags, ids, blocks)
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert g == w, (k, len(blocks[k]), sorted(set(g) - set(w))[:4], sorted(set(w) - set(g))[:4])
+    assert sum(len(w) for w in want) > 1000
+    # a set beyond 64 workgroups of 32: 256 expressions per workgroup, tables read from HBM
+    many = [f"lit{i:05d}x" for i in range(2100)] + ["status=[0-9]+", "a.c"]
+    mflags = [14] * 2100 + [6, 6]
+    mids = [i % 50 for i in range(2100)] + [50, 51]
+    mblocks = [b"lit00007x lit02099x status=200 abc\n", b"nothing here\n", filler[:2047], filler[:3000] + b"lit01234x\n"]
+    assert _hs_events(product, many, mflags, mids, mblocks) == _hs_events(oracle, many, mflags, mids, mblocks)
+
+
 def test_chunked_pipeline_matches_oracle(torch_cuda, monkeypatch):
     """Force the two-stream chunked pipeline (normally used above 512 MiB) on a 40 MiB text: chunk-crossing lines, carried
     line numbers and double-buffered candidate segments must give the same hits as the oracle."""
