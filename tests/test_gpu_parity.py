@@ -424,7 +424,7 @@ def test_face_a_short_block_regimes(torch_cuda):
     want = _hs_events(oracle, patterns, flags, ids, blocks)
     for k, (g, w) in enumerate(zip(got, want)):
         assert g == w, (k, len(blocks[k]), sorted(set(g) - set(w))[:4], sorted(set(w) - set(g))[:4])
-    assert sum(len(w) for w in want) > 1000
+    assert sum(len(w) for w in want) > 500
     # a set beyond 64 workgroups of 32: 256 expressions per workgroup, tables read from HBM
     many = [f"lit{i:05d}x" for i in range(2100)] + ["status=[0-9]+", "a.c"]
     mflags = [14] * 2100 + [6, 6]
