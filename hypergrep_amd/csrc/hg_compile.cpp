@@ -1220,23 +1220,28 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
   return 0;
 }
 
-// Packs context-free single-word always-on expressions into shared state words (HgSlowGroup): first fit by node count.
-// Members move to the front of db.slow, group by group; a group of one is not worth its tables.
+// Packs single-word always-on expressions into shared state words (HgSlowGroup): first fit by node count, the expressions
+// with boundary conditions first (their bins run the routine with conditions, and whatever context-free expression still
+// fits rides along), then the context-free ones (bins of their own once the others are full).
 void build_slow_groups(HgDb &db) {
   db.groups.clear();
   db.nslow_grouped = 0;
   if (std::getenv("HG_NO_SLOW_GROUPS")) return;
-  struct Bin { std::vector<uint32_t> members; uint32_t nodes = 0; };
+  const bool mixed = !std::getenv("HG_NO_CTX_GROUPS");
+  struct Bin { std::vector<uint32_t> members; uint32_t nodes = 0; bool ctx = false; };
   std::vector<Bin> bins;
-  for (uint32_t j = 0; j < db.nslow_fast; j++) {
-    const HgPattern &p = db.patterns[db.slow[j]];
-    if (!p.simple || p.nw != 1 || p.nnodes == 0) continue;
-    Bin *home = nullptr;
-    for (Bin &b : bins)
-      if (b.nodes + p.nnodes <= 32 && b.members.size() < HG_GROUP_MAX_MEMBERS) { home = &b; break; }
-    if (!home) { bins.emplace_back(); home = &bins.back(); }
-    home->members.push_back(db.slow[j]);
-    home->nodes += p.nnodes;
+  for (int pass = 0; pass < 2; pass++) {  // 0: expressions with conditions, 1: context-free ones
+    for (uint32_t j = 0; j < db.nslow_fast; j++) {
+      const HgPattern &p = db.patterns[db.slow[j]];
+      if (p.nw != 1 || p.nnodes == 0 || (p.simple != 0) != (pass == 1)) continue;
+      if (pass == 0 && !mixed) continue;
+      Bin *home = nullptr;
+      for (Bin &b : bins)
+        if (b.nodes + p.nnodes <= 32 && b.members.size() < HG_GROUP_MAX_MEMBERS) { home = &b; break; }
+      if (!home) { bins.emplace_back(); home = &bins.back(); home->ctx = pass == 0; }
+      home->members.push_back(db.slow[j]);
+      home->nodes += p.nnodes;
+    }
   }
   std::vector<uint32_t> grouped;
   for (const Bin &b : bins) {
@@ -1247,21 +1252,30 @@ void build_slow_groups(HgDb &db) {
     db.pool.resize(db.pool.size() + 256, 0);
     g.follow_off = static_cast<uint32_t>(db.pool.size());
     db.pool.resize(db.pool.size() + b.nodes, 0);
+    if (b.ctx) {
+      g.ctx_off = static_cast<uint32_t>(db.pool.size());
+      db.pool.resize(db.pool.size() + 36, 0);
+    }
     g.nnodes = b.nodes;
     g.nmembers = static_cast<uint32_t>(b.members.size());
     bool unbounded = false;
     uint32_t shift = 0;
     for (uint32_t m = 0; m < g.nmembers; m++) {
       const HgPattern &p = db.patterns[b.members[m]];
+      const uint32_t all = (p.nnodes == 32 ? 0xFFFFFFFFu : ((1u << p.nnodes) - 1u)) << shift;
       g.member[m] = b.members[m];
-      g.acc[m] = p.acc_all << shift;
+      g.acc[m] = b.ctx ? all : p.acc_all << shift;
       g.acc_all |= g.acc[m];
-      g.init_word |= p.init_word << shift;
+      g.init_word |= db.pool[p.init_off] << shift;
       if (p.single) g.single_mask |= 1u << m;
       if (p.max_len == 0) unbounded = true;
       g.max_len = std::max(g.max_len, p.max_len);
       for (uint32_t c = 0; c < 256; c++) db.pool[g.reach_off + c] |= db.pool[p.reach_off + c] << shift;
       for (uint32_t v = 0; v < p.nnodes; v++) db.pool[g.follow_off + shift + v] = db.pool[p.follow_off + v] << shift;
+      if (b.ctx) {
+        for (uint32_t i = 0; i < 16; i++) db.pool[g.ctx_off + i] |= db.pool[p.amask_off + i] << shift;
+        for (uint32_t i = 0; i < 20; i++) db.pool[g.ctx_off + 16 + i] |= db.pool[p.acc_off + i] << shift;
+      }
       shift += p.nnodes;
       grouped.push_back(b.members[m]);
     }

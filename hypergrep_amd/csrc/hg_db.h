@@ -97,9 +97,12 @@ struct HgWindow {
   uint32_t factor_off;  // factor index << 8 | off
 };
 
-// Several always-on expressions in ONE state word.  Context-free single-word automata whose nodes add up to <= 32 are
-// renumbered into one word (their follow sets stay disjoint), with the union of their reach / init tables: one pass of the
-// always-on kernel then advances all of them for the price of one, and only a match looks at which member accepted.
+// Several always-on expressions in ONE state word.  Single-word automata whose nodes add up to <= 32 are renumbered into
+// one word (their follow sets stay disjoint), with the union of their reach / init tables: one pass of the always-on kernel
+// then advances all of them for the price of one, and only a match looks at which member accepted.  A group of context-free
+// members runs the cheapest routine; as soon as one member has boundary conditions (\b, ^, $ ...) the group carries the
+// union of the members' per-context tables (ctx_off) and runs the routine with conditions — members without conditions
+// ride along for free.
 constexpr uint32_t HG_GROUP_MAX_MEMBERS = 8;
 struct HgSlowGroup {
   uint32_t reach_off;   // pool: reach[256] over the group's nodes
@@ -109,9 +112,11 @@ struct HgSlowGroup {
   uint32_t nmembers;
   uint32_t single_mask;  // bit m: member m has HS_FLAG_SINGLEMATCH
   uint32_t member[HG_GROUP_MAX_MEMBERS];  // pattern indices
-  uint32_t acc[HG_GROUP_MAX_MEMBERS];     // accepting nodes of each member
+  uint32_t acc[HG_GROUP_MAX_MEMBERS];     // context-free group: accepting nodes of each member; with conditions: ALL nodes of each member
+  uint32_t ctx_off;      // 0: context-free group; else pool: amask[4 previous][4 next] then acc[4 previous][5 next] over the group's nodes
+  uint32_t reserved;
 };
-static_assert(sizeof(HgSlowGroup) == 96, "HgSlowGroup layout");
+static_assert(sizeof(HgSlowGroup) == 104, "HgSlowGroup layout");
 
 HG_HD uint32_t hg_dot4(uint32_t v, uint32_t w) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -1384,11 +1384,17 @@ __device__ __forceinline__ void always_on_segment(const AlwaysOnCtx &a, const Hg
   }
 }
 
-template <bool SIMPLE>
-__device__ __forceinline__ void always_on_segment1(const AlwaysOnCtx &a, const HgPattern &p, uint32_t pi, const hgdev::lds_u32 *tab, uint64_t lo, uint64_t hi,
-                                                   uint64_t line_start, uint64_t bs1, uint32_t rank_lo) {
+// What a pass of the always-on kernel advances: one expression, or several packed into one state word (HgSlowGroup).
+// The members' pattern indices and node masks sit in the wave's table area (CT_MEMBER).
+struct AoUnit {
+  uint32_t init_word, acc_all, max_len, nmembers, single_mask, nnodes;
+};
+
+__device__ __forceinline__ void always_on_segment1(const AlwaysOnCtx &a, const AoUnit &p, const hgdev::lds_u32 *tab, uint64_t lo, uint64_t hi, uint64_t line_start,
+                                                   uint64_t bs1, uint32_t rank_lo) {
   if (lo >= hi) return;
   const hgdev::lds_u32 *reach = tab + CT_REACH, *fu = tab + CT_FU, *amask = tab + CT_AMASK, *acct = tab + CT_ACC;
+  const hgdev::lds_u32 *member = tab + CT_MEMBER, *member_nodes = tab + CT_MEMBER + HG_GROUP_MAX_MEMBERS;
   const uint8_t *text = a.text;
   uint64_t q = line_start;  // first byte the automaton sees (always_on_segment)
   if (p.max_len && p.max_len <= HG_ALWAYS_ON_FAST_MAX_LEN) {
@@ -1402,9 +1408,7 @@ __device__ __forceinline__ void always_on_segment1(const AlwaysOnCtx &a, const H
   const uint32_t span = stop - first;  // bytes r with r - first < span are consumed; r == stop only lends its context
   const bool text_ends = hi >= a.nbytes;
   const uint32_t nt = (p.nnodes + 7u) >> 3;  // follow-union tables in use (wave-uniform)
-  const uint32_t I = SIMPLE ? p.init_word : tab[CT_INIT];
-  const uint32_t acc_all = p.acc_all;
-  const bool single = p.single != 0;
+  const uint32_t I = p.init_word;
   uint32_t pc = HG_PC_START;
   if (q) {
     const uint32_t before = text[q - 1];
@@ -1424,7 +1428,15 @@ __device__ __forceinline__ void always_on_segment1(const AlwaysOnCtx &a, const H
     if (k && d == k * bs1) pc = HG_PC_START;
   }
   uint32_t rank = rank_lo, S = 0;
-  bool reported = false;
+  uint32_t reported = 0;  // bit m: member m has reported on this line (it matters for SINGLEMATCH members only)
+  // accepting nodes `hit` (rare) -> the members they belong to: mark, and note the match when it is this segment's to report
+  auto settle = [&](uint32_t hit, bool mark, bool report, uint64_t end) {
+    for (uint32_t m = 0; m < p.nmembers; m++) {
+      if (!(hit & member_nodes[m]) || ((p.single_mask & reported) >> m & 1u)) continue;
+      if (mark) reported |= 1u << m;
+      if (report) always_on_note(a, member[m], end, rank);
+    }
+  };
   // the lane's text arrives 16 bytes at a time, one load ahead (each is a memory round trip of its own: the lanes of a wave
   // read 256 bytes apart)
   auto load16 = [&](uint32_t at) { return (at <= stop && base + at < a.nbytes) ? *reinterpret_cast<const uint4 *>(text + base + at) : make_uint4(0, 0, 0, 0); };
@@ -1448,46 +1460,33 @@ __device__ __forceinline__ void always_on_segment1(const AlwaysOnCtx &a, const H
       const bool inside = consume || at_stop;
       const uint32_t c = (at_stop && text_ends) ? 0u : ((v >> (8 * i)) & 0xFFu);
       if (inside && r == next_break) {  // the piece ends before this byte: END context for a match ending here, then a fresh start
-        if (!SIMPLE) {
-          if ((S & acct[pc * 5 + HG_NC_END]) && r > own && !(single && reported)) always_on_note(a, pi, base + r, rank);
-        }
+        const uint32_t hit = S & acct[pc * 5 + HG_NC_END];
+        if (hit && r > own) settle(hit, false, true, base + r);
         S = 0;
         pc = HG_PC_START;
-        reported = false;
+        reported = 0;
         next_break = break_after(r);
       }
-      uint32_t cc = 0;
-      if (!SIMPLE) {
-        // a match can end before this byte; the byte decides the right-hand context (END at a NUL / the end of the text)
-        cc = c == '\n' ? HG_NC_NLFINAL : (hg_is_word(c) ? HG_NC_WORD : HG_NC_OTHER);
-        const uint32_t hit = inside ? (S & acct[pc * 5 + (c == 0 ? static_cast<uint32_t>(HG_NC_END) : cc)]) : 0u;
-        if (hit && !(single && reported)) {
-          reported = true;  // (a match that ends in an earlier segment is that segment's to report; it also settles this line)
-          if (r > own) always_on_note(a, pi, base + r, rank);
-        }
-      }
+      // a match can end before this byte; the byte decides the right-hand context (END at a NUL / the end of the text)
+      const uint32_t cc = c == '\n' ? HG_NC_NLFINAL : (hg_is_word(c) ? HG_NC_WORD : HG_NC_OTHER);
+      const uint32_t hit = inside ? (S & acct[pc * 5 + (c == 0 ? static_cast<uint32_t>(HG_NC_END) : cc)]) : 0u;
+      if (hit) settle(hit, true, r > own, base + r);  // (a match that ends in an earlier segment is that segment's to report; it also settles this line)
       uint32_t T = I | fu[S & 0xFFu];
       if (nt > 1) T |= fu[256 + ((S >> 8) & 0xFFu)];
       if (nt > 2) T |= fu[512 + ((S >> 16) & 0xFFu)];
       if (nt > 3) T |= fu[768 + (S >> 24)];
-      uint32_t Sn = T & rc[i];
-      if (!SIMPLE) Sn &= amask[pc * 4 + cc];
+      uint32_t Sn = T & rc[i] & amask[pc * 4 + cc];
       if (c == 0) Sn = 0;  // scanned bytes end here (or leading NULs are skipped): start afresh after it
       S = consume ? Sn : S;
-      if (SIMPLE) {
-        if (consume && (S & acc_all) && !(single && reported)) {
-          reported = true;
-          if (r >= own) always_on_note(a, pi, base + r + 1, rank);
-        }
-      }
       const bool nl = consume && c == '\n';
-      if (!SIMPLE) {  // a match that includes the newline ends the line: END context
-        if (nl && (S & acct[HG_PC_NL * 5 + HG_NC_END]) && r >= own && !(single && reported)) always_on_note(a, pi, base + r + 1, rank);
-        if (consume) pc = (nl || c == 0) ? static_cast<uint32_t>(HG_PC_START) : hg_prev_ctx(c);
+      if (nl) {  // a match that includes the newline ends the line: END context
+        const uint32_t hit_nl = S & acct[HG_PC_NL * 5 + HG_NC_END];
+        if (hit_nl && r >= own) settle(hit_nl, false, true, base + r + 1);
       }
+      if (consume) pc = (nl || c == 0) ? static_cast<uint32_t>(HG_PC_START) : hg_prev_ctx(c);
       rank += (nl && r >= own) ? 1u : 0u;
       S = nl ? 0u : S;
-      reported = nl ? false : reported;
+      reported = nl ? 0u : reported;
       next_break = nl ? break_after(r + 1) : next_break;
     }
   }
@@ -1495,10 +1494,6 @@ __device__ __forceinline__ void always_on_segment1(const AlwaysOnCtx &a, const H
 
 // The same for automata without boundary conditions (`simple`), the bulk of the always-on tier: only the bytes [first, stop)
 // matter (no context byte at `stop`), the text comes a dword at a time, and the per-byte work is a dozen selects.
-// What the pass advances: one expression, or several packed into one state word (HgSlowGroup).
-struct AoUnit {
-  uint32_t init_word, acc_all, max_len, nmembers, single_mask;
-};
 template <int NT>  // follow-union tables in use: ceil(nodes / 8)
 __device__ __forceinline__ void always_on_simple(const AlwaysOnCtx &a, const AoUnit &p, const hgdev::lds_u32 *tab, uint64_t lo, uint64_t hi, uint64_t line_start,
                                                  uint64_t bs1, uint32_t rank_lo) {
@@ -1594,6 +1589,10 @@ __global__ __launch_bounds__(256) void hg_always_on_fast_kernel(HgConfirmArgs a)
         tab[CT_MEMBER + lane] = g.member[lane];
         tab[CT_MEMBER + HG_GROUP_MAX_MEMBERS + lane] = lane < g.nmembers ? g.acc[lane] : 0u;
       }
+      if (g.ctx_off) {  // a group with boundary conditions: the union of the members' per-context tables
+        if (lane < 16) tab[CT_AMASK + lane] = a.db.pool[g.ctx_off + lane];
+        if (lane < 20) tab[CT_ACC + lane] = a.db.pool[g.ctx_off + 16 + lane];
+      }
       nnodes = g.nnodes;
       one_word = true;
     } else {
@@ -1603,7 +1602,7 @@ __global__ __launch_bounds__(256) void hg_always_on_fast_kernel(HgConfirmArgs a)
       else stage_tables<true>(tab, a.db.pool, p, p.nw, lane);
       if (lane == 0) {
         tab[CT_MEMBER] = pi;
-        tab[CT_MEMBER + HG_GROUP_MAX_MEMBERS] = p.acc_all;
+        tab[CT_MEMBER + HG_GROUP_MAX_MEMBERS] = p.simple ? p.acc_all : 0xFFFFFFFFu;  // (with conditions: the nodes of the member, i.e. all)
       }
       nnodes = p.nnodes;
       one_word = p.nw == 1;
@@ -1652,9 +1651,10 @@ __global__ __launch_bounds__(256) void hg_always_on_fast_kernel(HgConfirmArgs a)
       if (!one_unit) stage(u);
       if (u < ngroups) {
         const HgSlowGroup &g = a.db.groups[u];
-        const AoUnit unit{g.init_word, g.acc_all, g.max_len, g.nmembers, g.single_mask};
+        const AoUnit unit{g.init_word, g.acc_all, g.max_len, g.nmembers, g.single_mask, g.nnodes};
         const uint32_t nt = (g.nnodes + 7u) >> 3;
-        if (nt <= 1) always_on_simple<1>(cx, unit, tab, lo, hi, line_start, a.bs1, rank_lo);
+        if (g.ctx_off) always_on_segment1(cx, unit, tab, lo, hi, line_start, a.bs1, rank_lo);
+        else if (nt <= 1) always_on_simple<1>(cx, unit, tab, lo, hi, line_start, a.bs1, rank_lo);
         else if (nt == 2) always_on_simple<2>(cx, unit, tab, lo, hi, line_start, a.bs1, rank_lo);
         else always_on_simple<4>(cx, unit, tab, lo, hi, line_start, a.bs1, rank_lo);
         continue;
@@ -1662,13 +1662,13 @@ __global__ __launch_bounds__(256) void hg_always_on_fast_kernel(HgConfirmArgs a)
       const uint32_t pi = a.db.slow[a.db.nslow_grouped + (u - ngroups)];
       const HgPattern &p = a.db.patterns[pi];
       if (p.simple) {
-        const AoUnit unit{p.init_word, p.acc_all, p.max_len, 1u, p.single ? 1u : 0u};
+        const AoUnit unit{p.init_word, p.acc_all, p.max_len, 1u, p.single ? 1u : 0u, p.nnodes};
         const uint32_t nt = (p.nnodes + 7u) >> 3;  // wave-uniform
         if (nt <= 1) always_on_simple<1>(cx, unit, tab, lo, hi, line_start, a.bs1, rank_lo);
         else if (nt == 2) always_on_simple<2>(cx, unit, tab, lo, hi, line_start, a.bs1, rank_lo);
         else always_on_simple<4>(cx, unit, tab, lo, hi, line_start, a.bs1, rank_lo);
       }
-      else if (p.nw == 1) always_on_segment1<false>(cx, p, pi, tab, lo, hi, line_start, a.bs1, rank_lo);
+      else if (p.nw == 1) always_on_segment1(cx, AoUnit{p.init_word, p.acc_all, p.max_len, 1u, p.single ? 1u : 0u, p.nnodes}, tab, lo, hi, line_start, a.bs1, rank_lo);
       else always_on_segment<2, false>(cx, p, pi, tab, lo, hi, line_start, a.bs1, rank_lo);
     }
   }

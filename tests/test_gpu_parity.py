@@ -1060,6 +1060,47 @@ def test_always_on_expressions_share_a_state_word(torch_cuda):
         assert got == want and stats.n_lines == nlines
 
 
+def test_always_on_groups_with_boundary_conditions(torch_cuda, monkeypatch):
+    """Always-on expressions with boundary conditions (\\b \\B ^ $, with and without MULTILINE) share state words too: their
+    groups carry the union of the per-context tables, and context-free expressions ride along.  More expressions than one
+    word holds (several groups), SINGLEMATCH and all-matches members, shared ids, NUL bytes, over-long lines, small scan
+    buffers; the same set without the packing must give the same hits."""
+    from hypergrep_amd import device
+
+    rng = random.Random(909)
+    pats = ["\\bq[a-z]*z\\b", "^[A-Z]", "[0-9]$", "\\b[0-9]{3}\\b", "\\Bz", "x[0-9]+y", "=7", "^ab", "\\b[a-c]{2}\\b", "[xyz]$", "\\bq\\B", "^[0-9]+\\.", "[_-][xyz]?[019]", "\\b[A-Z]{2}-",
+            "[a-z]+@[a-z]+"]
+    flags = [14, 14, 6, 14, 6, 14, 14, 10, 6, 14, 14, 6, 6, 14, 14]
+    ids = [0, 1, 2, 2, 3, 4, 5, 6, 7, 7, 8, 9, 0, 10, 11]
+    words = ["joe@host", "x12y", "AB-12:", "qz", "quiz", "3.14", "=7", "_x0", "-9", "ab", "cab", "123", "1234", "q", "qq", "Zz", "z", "xyz", "7"]
+    lines = []
+    for _ in range(3000):
+        n = rng.randint(0, 7)
+        lines.append(" ".join(rng.choice(words) if rng.random() < 0.5 else "".join(rng.choice("abqxyzABC019.@=-_: ") for _ in range(rng.randint(1, 9))) for _ in range(n)))
+    data = ("\n".join(lines) + "\n").encode()
+    data = data[:30000] + b"\0" + data[30000:60000] + b"q" * 3000 + b"z 123 " + b"h" * 2500 + b"9\n" + data[60000:] + b"ab 12"
+    db = device.Database(pats, flags, ids)
+    info = db.info()
+    assert info["n_always_on"] == len(pats) and info["max_state_words"] == 1
+    for bs in (262140, 1000, 64):
+        want, nlines = oracle_hits(data, pats, flags, ids, buffer_size=bs)
+        got, stats = gpu_scan_buffer(torch_cuda, data, pats, flags, ids, buffer_size=bs)
+        assert stats.n_lines == nlines
+        assert got == want, bs
+        assert len(want) > 3000
+    want, _ = oracle_hits(data, pats, flags, ids)
+    monkeypatch.setenv("HG_NO_CTX_GROUPS", "1")
+    got, _ = gpu_scan_buffer(torch_cuda, data, pats, flags, ids)
+    assert got == want
+    monkeypatch.delenv("HG_NO_CTX_GROUPS")
+    # a single group with conditions (tables stay staged), and one expression with conditions beside a context-free group
+    for sub in ([0, 3, 5], [3, 5, 6, 14], [1, 2]):
+        p, f, i = [pats[k] for k in sub], [flags[k] for k in sub], [ids[k] for k in sub]
+        want, nlines = oracle_hits(data, p, f, i)
+        got, stats = gpu_scan_buffer(torch_cuda, data, p, f, i)
+        assert got == want and stats.n_lines == nlines, sub
+
+
 def test_dense_candidates_shrink_the_pipeline_chunks(torch_cuda, monkeypatch):
     """A text whose every dword is a candidate: the workspace holds ONE pipeline chunk's candidates, and when that would pass
     the limit (2^30 records; lowered here) the engine halves the chunks instead of failing with "split the buffer".
