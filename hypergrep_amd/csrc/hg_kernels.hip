@@ -1915,16 +1915,20 @@ __global__ __launch_bounds__(256) void hg_fin_sort_small_kernel(const HgHit *hit
   // A bucket's fill level and its first 64 records are loaded TOGETHER (lanes past the fill level read records of the same
   // region that are simply not used), and one bucket ahead: the loads of bucket b + waves are in flight while bucket b is
   // ordered.  Per bucket the wave then pays the sorting network, not two memory round trips.
-  const HgHit none{0, 0, 0};
+  // (the record travels as the four dwords it is: a struct selected by a condition went through scratch memory)
+  const uint4 *hits4 = reinterpret_cast<const uint4 *>(hits);
+  static_assert(sizeof(HgHit) == 16, "one 16-byte load per record");
   uint32_t b = b_lo + wave;
   uint32_t n_next = b < b_hi ? fill[b] : 0u;
-  HgHit h_next = (b < b_hi && lane < cap) ? hits[static_cast<uint64_t>(b) * cap + lane] : none;
+  uint4 h_next = make_uint4(0, 0, 0, 0);
+  if (b < b_hi && lane < cap) h_next = hits4[static_cast<uint64_t>(b) * cap + lane];
   for (; b < b_hi; b += waves) {
     uint32_t n = n_next;
-    const HgHit h = h_next;
+    const uint4 hv = h_next;
     const uint32_t bn = b + waves;
     n_next = bn < b_hi ? fill[bn] : 0u;
-    h_next = (bn < b_hi && lane < cap) ? hits[static_cast<uint64_t>(bn) * cap + lane] : none;
+    h_next = make_uint4(0, 0, 0, 0);
+    if (bn < b_hi && lane < cap) h_next = hits4[static_cast<uint64_t>(bn) * cap + lane];
     if (n > cap) n = cap;  // (overflowed: the pass is repeated anyway)
     if (n > 64) {  // hg_fin_sort_big_kernel's: noted in its work list
       if (lane == 0) big_list[atomicAdd(big_count, 1u)] = b;
@@ -1935,24 +1939,25 @@ __global__ __launch_bounds__(256) void hg_fin_sort_small_kernel(const HgHit *hit
       continue;
     }
     const uint32_t b0 = b * cap;
+    const HgHit h{(static_cast<uint64_t>(hv.y) << 32) | hv.x, hv.z, hv.w};
     uint64_t k = lane < n ? fin_key(h, id_bits, to_bits) : ~0ull;  // (padding sorts last; a real key never has all bits set)
     uint32_t x = b0 + lane;
     if (n > 1) {
-#pragma unroll
-      for (uint32_t kk = 2; kk <= 64; kk <<= 1) {
-#pragma unroll
-        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
-          const uint32_t lo32 = __shfl_xor(static_cast<uint32_t>(k), j, 64), hi32 = __shfl_xor(static_cast<uint32_t>(k >> 32), j, 64);
-          const uint64_t other = (static_cast<uint64_t>(hi32) << 32) | lo32;
-          const uint32_t ox = __shfl_xor(x, j, 64);
-          const bool lower = (lane & j) == 0, up = (lane & kk) == 0;
-          const bool take = (lower == up) ? (other < k) : (other > k);  // ascending run: the lower lane keeps the smaller key
-          if (take) {
-            k = other;
-            x = ox;
-          }
-        }
+      // Order by RANK: every lane counts the keys below its own (equal keys: the lower lane first) against the n keys
+      // broadcast one after the other (v_readlane, n is wave-uniform), then one permute puts key and index in their places.
+      // ~8 instructions per key and no LDS traffic; the bitonic network over the lanes this replaces was 21 stages of three
+      // cross-lane moves each, ~2500 instructions per bucket, and the kernel was bound by exactly that.
+      const uint32_t klo = static_cast<uint32_t>(k), khi = static_cast<uint32_t>(k >> 32);
+      const uint32_t nu = __builtin_amdgcn_readfirstlane(n);
+      uint32_t rank = 0;
+      for (uint32_t i = 0; i < nu; i++) {
+        const uint64_t ki = (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(khi, i))) << 32) | static_cast<uint32_t>(__builtin_amdgcn_readlane(klo, i));
+        rank += (ki < k || (ki == k && i < lane)) ? 1u : 0u;
       }
+      if (lane >= nu) rank = lane;  // (padding stays where it is: ranks are a permutation of the lanes)
+      const uint32_t slo = __builtin_amdgcn_ds_permute(rank << 2, klo), shi = __builtin_amdgcn_ds_permute(rank << 2, khi);
+      x = __builtin_amdgcn_ds_permute(rank << 2, x);
+      k = (static_cast<uint64_t>(shi) << 32) | slo;
     }
     const uint32_t plo = __shfl_up(static_cast<uint32_t>(k), 1, 64), phi = __shfl_up(static_cast<uint32_t>(k >> 32), 1, 64);
     const uint64_t prev = (static_cast<uint64_t>(phi) << 32) | plo;
