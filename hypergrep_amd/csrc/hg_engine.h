@@ -31,7 +31,9 @@ struct HgDeferred {
 //   of the finalize, [32, 36) tile-scan state (HgTileBase)
 enum { HG_ST_FIN_TOTAL = 24, HG_ST_SELECTED = 28, HG_ST_FINAL = 32, HG_ST_WORDS = 36, HG_ST_ZERO_WORDS = 32,
        HG_ST_BLOCK_DONE = 40 };  // (outside the words a pass resets: workgroups of hg_block_small_kernel that have finished)
-enum { HG_CNT_CANDS = 0, HG_CNT_HITS = 1, HG_CNT_CAND_NEED = 2, HG_CNT_HIT_NEED = 3, HG_CNT_DEFER_NEED = 4, HG_CNT_WORDS = 8,
+enum { HG_CNT_CANDS = 0, HG_CNT_HITS = 1, HG_CNT_CAND_NEED = 2, HG_CNT_HIT_NEED = 3, HG_CNT_DEFER_NEED = 4,
+       HG_CNT_HITS_WRAPPED = 5,  // the 32-bit hit counter went round (direct appends): the buffer is scanned in segments instead
+       HG_CNT_WORDS = 8,
        HG_CNT_CURSOR0 = 8,      // one tile cursor per pipeline chunk follows the counters proper
        HG_CNT_ALL_WORDS = 8 + 16 };
 constexpr uint32_t HG_STREAM_GRAB = 2 * HG_STREAM_WG_WAVES_DEFAULT;  // tiles per draw of a stream workgroup: two per wave
@@ -94,6 +96,9 @@ struct HgConfirmArgs {
   uint32_t bucket_shift, bucket_cap;
   uint32_t *bucket_fill;
   uint32_t *counters;
+  // A pass reports the pieces whose first scanned byte lies in [own_lo, own_hi): the whole buffer normally; one segment of it
+  // when the buffer is scanned in several passes (HgScanner::scan_segments).  Buckets count from own_lo.
+  uint64_t own_lo, own_hi;
 };
 constexpr uint32_t HG_BLOCK_SMALL_POOL = 10240;  // ... words of automaton tables a workgroup of that path stages in LDS (40 KiB)
 constexpr uint32_t HG_BLOCK_SLICED_MAX = 2047;   // ... blocks up to this many bytes are split over the lanes by start position
@@ -141,7 +146,15 @@ class HgScanner {
   int alloc_cands(uint64_t n);
   int alloc_hits(uint64_t n);
   int scan_impl(const void *d_text, uint64_t nbytes, int buffer_size, uint64_t line_base, bool block_mode, hipStream_t stream, HgScanOutput *out);
-  int run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint64_t line_base, bool block_mode, hipStream_t stream, HgScanOutput *out,
+  // One pass over the tiles [tile_lo, tile_hi) of the text: the whole buffer, or a segment of it (scan_segments).  The tile
+  // scan starts from (cs0, piece0): the start of the line that contains the range's first byte and that line's piece index;
+  // only pieces whose first scanned byte lies in [own_lo, own_hi) are reported.
+  struct PassRange {
+    uint64_t tile_lo, tile_hi, cs0, piece0, own_lo, own_hi;
+    bool last;  // the range ends with the text: the pass leaves the final piece count
+  };
+  int scan_segments(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint64_t line_base, hipStream_t stream, HgScanOutput *out, uint32_t nsegments, bool *too_many);
+  int run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint64_t line_base, const PassRange &range, bool block_mode, hipStream_t stream, HgScanOutput *out,
                bool *overflow);
   bool fail(hipError_t e, const char *what);
 
@@ -169,6 +182,9 @@ class HgScanner {
   uint32_t *d_defer_count_ = nullptr;
   HgHit *d_hits_raw_ = nullptr, *d_hits_out_ = nullptr;
   HgHitAux *d_aux_raw_ = nullptr, *d_aux_out_ = nullptr;
+  HgHit *d_acc_hits_ = nullptr;  // segmented scans: the segments' ordered hits, one after the other
+  HgHitAux *d_acc_aux_ = nullptr;
+  uint64_t acc_cap_ = 0;
   uint64_t *d_key_a_ = nullptr, *d_key_b_ = nullptr;
   uint32_t *d_perm_a_ = nullptr, *d_perm_b_ = nullptr;
   uint8_t *d_keep_ = nullptr;

@@ -30,7 +30,7 @@ __global__ void hg_block_mark_kernel(HgConfirmArgs a, uint32_t *pattern_flags);
 __global__ void hg_block_scan_kernel(HgConfirmArgs a, const uint32_t *pattern_flags);
 __global__ void hg_block_small_kernel(HgDbView db, const uint8_t *h_text, uint32_t length, HgHit *h_out, uint32_t seg_cap, uint32_t *h_counts, uint32_t *d_done,
                                       uint32_t *h_flag, uint32_t seq, uint32_t ppw);
-__global__ void hg_reset_kernel(uint32_t *state, uint32_t state_words, HgTileBase *final_state, uint64_t line_base, uint32_t *fill, uint32_t nb, uint32_t *defer_count,
+__global__ void hg_reset_kernel(uint32_t *state, uint32_t state_words, HgTileBase *final_state, uint64_t carry_start, uint64_t first_piece, uint32_t *fill, uint32_t nb, uint32_t *defer_count,
                                 uint32_t ndefer);
 __global__ void hg_fin_sort_small_kernel(const HgHit *hits, uint32_t *idx, const uint32_t *fill, uint32_t b_lo, uint32_t b_hi, uint32_t cap, uint32_t id_bits,
                                          uint32_t to_bits, uint32_t *kept_count, uint32_t *big_list, uint32_t *big_count);
@@ -157,7 +157,7 @@ HgScanner::~HgScanner() {
   (void)hipSetDevice(device_);
   void *ptrs[] = {d_patterns_, d_pool_, d_factors_, d_windows_, d_bucket_, d_filter_, d_ext_, d_slow_, d_sums_, d_bases_, d_block_base_,
                   d_agg_, d_cands_, d_hits_raw_, d_hits_out_, d_aux_raw_, d_aux_out_,
-                  d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, d_keep_, d_counters_, d_temp_, d_seg_count_, d_pflags_, d_deferred_, d_defer_count_, d_seg_count2_, d_cands2_, d_disc_, d_bucket2_, d_windows2_, d_groups_};
+                  d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, d_keep_, d_counters_, d_temp_, d_seg_count_, d_pflags_, d_deferred_, d_defer_count_, d_seg_count2_, d_cands2_, d_disc_, d_bucket2_, d_windows2_, d_groups_, d_acc_hits_, d_acc_aux_};
   for (void *p : ptrs) hgmem::dev_free(p, "scanner");
   hgmem::host_free(h_counters_, "h_counters_");
   for (auto &ev : ev_)
@@ -243,10 +243,16 @@ int HgScanner::ensure(uint64_t nbytes) {
   return HG_OK;
 }
 
-int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint64_t line_base, bool block_mode, hipStream_t stream,
+// (internal) the pass would need more hit records or pipeline chunks than one pass may have: the caller scans in segments
+constexpr int HG_SPLIT = 1000;
+
+int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint64_t line_base, const PassRange &range, bool block_mode, hipStream_t stream,
                         HgScanOutput *out, bool *overflow) {
   *overflow = false;
-  const uint64_t ntiles = (nbytes + HG_TILE_BYTES - 1) / HG_TILE_BYTES;
+  const uint64_t tile_lo = range.tile_lo, tile_hi = range.tile_hi;
+  const uint64_t ntiles = tile_hi - tile_lo;  // tiles of this pass
+  // the bytes whose pieces this pass reports (buckets of the finalize count from own_lo)
+  const uint64_t own_end = std::min<uint64_t>(range.own_hi, nbytes), own_len = own_end > range.own_lo ? own_end - range.own_lo : 0;
 #define HG_TRY(call, what) \
   if (fail((call), what)) return HG_ERR_HIP;
   HG_TRY(hipEventRecord(ev_[0], stream), "event");
@@ -256,12 +262,12 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   // As many buckets as give ~30-50 records each (one wave orders up to 64 in registers; larger buckets go through LDS): from
   // the last pass's hits, else one hit per 8 KiB of text as a first guess.
   uint32_t fin_shift = 12, fin_nb = 1;
-  if (nbytes) {
-    const uint64_t expect = std::max<uint64_t>(fin_expect_hits_, nbytes >> 13);
+  if (own_len) {
+    const uint64_t expect = std::max<uint64_t>(fin_expect_hits_, own_len >> 13);
     uint64_t want_nb = 1;
     while (want_nb * 48 < expect && want_nb < HG_FIN_MAX_BUCKETS) want_nb <<= 1;
-    while (((nbytes - 1) >> fin_shift) >= want_nb) fin_shift++;
-    fin_nb = static_cast<uint32_t>((nbytes - 1) >> fin_shift) + 1;
+    while (((own_len - 1) >> fin_shift) >= want_nb) fin_shift++;
+    fin_nb = static_cast<uint32_t>((own_len - 1) >> fin_shift) + 1;
   }
   const uint32_t fin_cap = hit_cap_ / fin_nb;
   // (sort key of a bucket: line start inside the bucket | id | to | single; the raw records carry that start in the top
@@ -272,7 +278,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   // one launch puts the device state in place (counters, cursors, finalize totals, tile-scan state, bucket fill levels, the
   // first chunk's verified-occurrence counts)
   hipLaunchKernelGGL(hg_reset_kernel, dim3(std::max<uint32_t>(1, std::min<uint32_t>((fin_nb + 255) / 256, 256))), dim3(256), 0, stream, d_counters_, static_cast<uint32_t>(HG_ST_ZERO_WORDS), d_final_,
-                     line_base, d_fin_fill_, bucketed ? fin_nb : 0u, d_defer_count_, static_cast<uint32_t>(HG_CONFIRM_MODES * HG_DEFER_SHARDS));
+                     range.cs0, range.piece0, d_fin_fill_, bucketed ? fin_nb : 0u, d_defer_count_, static_cast<uint32_t>(HG_CONFIRM_MODES * HG_DEFER_SHARDS));
   HG_TRY(hipGetLastError(), "reset launch");
 
   // Chunked pipeline (line mode, large buffers): the text is cut into tile-aligned chunks; the stream pass of chunk c+1
@@ -291,12 +297,9 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   }
   if (!block_mode && chunk_limit_tiles_ && chunk_tiles > chunk_limit_tiles_) chunk_tiles = chunk_limit_tiles_;  // (a chunk's candidates did not fit before)
   nchunks = ntiles ? static_cast<uint32_t>((ntiles + chunk_tiles - 1) / chunk_tiles) : 1;
-  if (nchunks > static_cast<uint32_t>(kMaxChunks)) {
-    err_ = "the buffer needs more pipeline chunks than the scanner has: split the buffer";
-    return HG_ERR_ARG;
-  }
+  if (nchunks > static_cast<uint32_t>(kMaxChunks)) return HG_SPLIT;  // (chunks that shrank for a dense text: fewer tiles per pass then)
   std::vector<uint64_t> cut(nchunks + 1);  // chunk c = tiles [cut[c], cut[c + 1])
-  for (uint32_t c = 0; c <= nchunks; c++) cut[c] = std::min<uint64_t>(static_cast<uint64_t>(c) * chunk_tiles, ntiles);
+  for (uint32_t c = 0; c <= nchunks; c++) cut[c] = std::min<uint64_t>(tile_lo + static_cast<uint64_t>(c) * chunk_tiles, tile_hi);
   if (const char *env = std::getenv("HG_CHUNK_WEIGHTS")) {  // experiment: relative chunk sizes, e.g. "10,10,8,4"
     std::vector<double> w;
     for (const char *q = env; *q;) {
@@ -310,12 +313,12 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       double total = 0, run = 0;
       for (double v : w) total += v;
       nchunks = static_cast<uint32_t>(w.size());
-      cut.assign(nchunks + 1, 0);
+      cut.assign(nchunks + 1, tile_lo);
       chunk_tiles = 0;
       for (uint32_t c = 0; c < nchunks; c++) {
         run += w[c];
-        uint64_t end = c + 1 == nchunks ? ntiles : static_cast<uint64_t>(static_cast<double>(ntiles) * run / total) / TS_BLOCK_TILES * TS_BLOCK_TILES;
-        end = std::min<uint64_t>(std::max<uint64_t>(end, cut[c] + TS_BLOCK_TILES), ntiles);
+        uint64_t end = c + 1 == nchunks ? tile_hi : tile_lo + static_cast<uint64_t>(static_cast<double>(ntiles) * run / total) / TS_BLOCK_TILES * TS_BLOCK_TILES;
+        end = std::min<uint64_t>(std::max<uint64_t>(end, cut[c] + TS_BLOCK_TILES), tile_hi);
         cut[c + 1] = end;
         chunk_tiles = std::max<uint64_t>(chunk_tiles, end - cut[c]);
       }
@@ -432,6 +435,8 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       ca.bucket_shift = fin_shift;
       ca.bucket_fill = d_fin_fill_;
       ca.counters = d_counters_;
+      ca.own_lo = range.own_lo;
+      ca.own_hi = range.own_hi;
       if (block_mode) {
         HG_TRY(hipMemsetAsync(d_pflags_, 0, db_->patterns.size() * 4, side), "memset pattern flags");
         if (has_anchored) hipLaunchKernelGGL(hg_block_mark_kernel, dim3(segs_c), dim3(256), 0, side, ca, d_pflags_);
@@ -499,7 +504,8 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
         // themselves by then); only the last chunk's buckets remain for after those.  (Finalizing a chunk's buckets beside
         // the NEXT chunk's stream pass was tried: it slowed the stream pass by more than it saved.)
         const uint64_t prev_end = std::min<uint64_t>(t0 << HG_TILE_SHIFT, nbytes);  // a later hit's line starts less than bs1 bytes before it
-        const uint32_t lim = static_cast<uint32_t>(std::min<uint64_t>((prev_end > bs1 ? prev_end - bs1 : 0) >> fin_shift, fin_nb));
+        const uint64_t settled = prev_end > bs1 ? prev_end - bs1 : 0;           // ... pieces that start below this have all their hits
+        const uint32_t lim = static_cast<uint32_t>(std::min<uint64_t>((settled > range.own_lo ? settled - range.own_lo : 0) >> fin_shift, fin_nb));
         if (lim > fin_done) {
           HG_TRY(hipStreamWaitEvent(stream, ev_side_done_[c - 1], 0), "stream wait");  // the earlier chunks' hits are all in their buckets
           HG_TRY(hipStreamWaitEvent(stream, ev_tile_done_, 0), "stream wait");        // ... and the last chunk's tile scan (a one-block latency chain) is through
@@ -537,6 +543,11 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   const uint64_t cand_need = h_counters_[HG_CNT_CAND_NEED], hit_need = h_counters_[HG_CNT_HIT_NEED];
   const uint64_t defer_need = h_counters_[HG_CNT_DEFER_NEED];
   const bool fin_overflow = bucketed && h_counters_[HG_ST_SELECTED + 1] != 0;  // a bucket beyond what one block sorts
+  // Hit records one pass may hold (2^28: 8 GiB each of raw and ordered records); a buffer with more is scanned in segments
+  // whose ordered hits are put one after the other (scan_segments).
+  uint64_t kHitLimit = 1ull << 28;
+  if (const char *env = std::getenv("HG_HIT_LIMIT")) kHitLimit = std::max<uint64_t>(1u << 10, std::strtoull(env, nullptr, 10));  // (tests)
+  if (!block_mode && (n_raw > kHitLimit || h_counters_[HG_CNT_HITS_WRAPPED])) return HG_SPLIT;
   if (cand_need || defer_need || hit_need || fin_overflow || (!bucketed && n_raw > hit_cap_)) {
     // a private segment, a bucket or the compact hit array was too small: grow and let the caller repeat the pass
     if (cand_need || defer_need) {
@@ -553,7 +564,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       if (want > kCandLimit) {
         const uint64_t cur = (std::min<uint64_t>(chunk_tiles, ntiles) + TS_BLOCK_TILES - 1) / TS_BLOCK_TILES * TS_BLOCK_TILES;
         if (block_mode || cur <= TS_BLOCK_TILES) {
-          err_ = "more than 2^30 candidates in 16 MiB of text: split the buffer";
+          err_ = "the candidate limit is below what one 16 MiB chunk of this text produces";  // (only with HG_CAND_LIMIT lowered: 16 MiB hold 2^24 positions)
           return HG_ERR_ARG;
         }
         chunk_limit_tiles_ = std::max<uint64_t>(TS_BLOCK_TILES, cur / 2 / TS_BLOCK_TILES * TS_BLOCK_TILES);
@@ -587,9 +598,11 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
         hit_direct_ = true;
         want = std::min<uint64_t>(want, std::max<uint64_t>(by_total, std::min<uint64_t>(16 * by_total, kSegmentLimit)));
       }
-      want = std::max<uint64_t>(want, static_cast<uint64_t>(hit_cap_) * 2);
-      if (want > 0x7FFFFFF0u) {
-        err_ = "more than 2^31 hits in one scan call: split the buffer";
+      const uint64_t most = kHitLimit + kHitLimit / 4 + 4096;
+      want = std::max<uint64_t>(want, std::min<uint64_t>(static_cast<uint64_t>(hit_cap_) * 2, most));
+      if (want > most) {
+        if (!block_mode) return HG_SPLIT;
+        err_ = "more than 2^28 reports for one block";  // (block mode: one scan unit of at most 2 GiB, nothing to cut at)
         return HG_ERR_ARG;
       }
       int rc = alloc_hits(want);
@@ -600,14 +613,15 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   }
 
   fin_expect_hits_ = n_raw;
-  uint64_t n_pieces = block_mode ? 1 : h_final_->L - line_base + (nbytes > h_final_->cs ? hg_pieces(nbytes - h_final_->cs, bs1) : 0);
+  // (a pass that stops short of the text's end leaves no piece count: scan_segments takes it from its last pass)
+  uint64_t n_pieces = block_mode ? 1 : !range.last ? 0 : h_final_->L - line_base + (nbytes > h_final_->cs ? hg_pieces(nbytes - h_final_->cs, bs1) : 0);
   uint32_t n = static_cast<uint32_t>(n_raw);
   uint32_t kept = 0;
   if (n && !bucketed) {  // compact array + library sort (scanners that left bucketed emission, keys wider than 64 bits)
     const HgPattern *pats = static_cast<const HgPattern *>(d_patterns_);
     uint32_t blocks = (n + 255) / 256;
     // order by (line, id, to, single-after-multi): one radix sort over exactly the bits in use when they fit in 64, else two
-    const uint32_t line_bits = bits_for(line_base + n_pieces + 1);
+    const uint32_t line_bits = bits_for(line_base + (range.last ? n_pieces : nbytes) + 1);
     const uint32_t *perm = nullptr;
     uint32_t *pos = nullptr;
     size_t tb = temp_bytes_;
@@ -685,10 +699,14 @@ int HgScanner::scan_impl(const void *d_text, uint64_t nbytes, int buffer_size, u
   if (hgmem::log_file()) hgmem::note("scan  %p text %p .. %p  %llu  bs %d block %d\n", static_cast<void *>(this), d_text, static_cast<const void *>(static_cast<const char *>(d_text) + nbytes), static_cast<unsigned long long>(nbytes), buffer_size, block_mode ? 1 : 0);
   int rc = ensure(nbytes);
   if (rc) return rc;
+  const uint8_t *text = static_cast<const uint8_t *>(d_text);
+  const uint64_t ntiles = (nbytes + HG_TILE_BYTES - 1) / HG_TILE_BYTES;
+  const PassRange whole{0, ntiles, 0, line_base, 0, ~0ull, true};
   uint32_t reruns = 0;
   for (;;) {
     bool overflow = false;
-    rc = run_once(static_cast<const uint8_t *>(d_text), nbytes, bs1, line_base, block_mode, stream, out, &overflow);
+    rc = run_once(text, nbytes, bs1, line_base, whole, block_mode, stream, out, &overflow);
+    if (rc == HG_SPLIT) break;
     if (rc) return rc;
     if (!overflow) break;
     if (++reruns > 16) {
@@ -697,6 +715,116 @@ int HgScanner::scan_impl(const void *d_text, uint64_t nbytes, int buffer_size, u
     }
     if (std::getenv("HG_VERBOSE")) std::fprintf(stderr, "hypergrep_amd: workspace grown (cands %u, hits %u), repeating the pass\n", cand_cap_, hit_cap_);
   }
+  if (rc == HG_SPLIT) {
+    // More reports (or pipeline chunks) than one pass may have: the buffer is scanned in 2, 4, 8 ... segments.
+    for (uint32_t nsegments = 2;; nsegments *= 2) {
+      bool too_many = false;
+      rc = scan_segments(text, nbytes, bs1, line_base, stream, out, nsegments, &too_many);
+      if (rc) return rc;
+      if (!too_many) break;
+      if (nsegments >= (1u << 16)) {
+        err_ = "a single stretch of the text holds more reports than one pass may have";
+        return HG_ERR_NOMEM;
+      }
+    }
+  }
   out->reruns = reruns;
+  return HG_OK;
+}
+
+// The buffer in `nsegments` passes.  Segment s reports the pieces whose first scanned byte lies in its stretch of the text
+// (whole tiles) and scans on past the stretch's end for as long as such a piece can reach (bs1 bytes);
+// hits of pieces that belong to a neighbour are dropped where they are emitted (HitSink::push), so every piece is ordered
+// and filtered (SINGLEMATCH / duplicate rules) in exactly one pass.  The tile-scan state (carry-in line start, piece index)
+// at a segment's first tile is read from the previous pass, which has scanned past it.  The passes' ordered hits are put one
+// after the other: segments are in text order, so is their concatenation.  *too_many: some segment still overflowed a pass.
+int HgScanner::scan_segments(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint64_t line_base, hipStream_t stream, HgScanOutput *out, uint32_t nsegments,
+                             bool *too_many) {
+  *too_many = false;
+  const uint64_t ntiles = (nbytes + HG_TILE_BYTES - 1) / HG_TILE_BYTES;
+  const uint64_t reach = (bs1 >> HG_TILE_SHIFT) + 2;  // tiles a piece that starts inside a stretch can extend past its end
+  constexpr uint64_t kAlign = 16;  // (tiles; real segments are gigabytes)
+  const uint64_t seg_tiles = ((ntiles + nsegments - 1) / nsegments + kAlign - 1) / kAlign * kAlign;
+  if (seg_tiles <= reach) {  // (scan buffers of gigabytes on a text that needs many segments)
+    err_ = "more reports than one pass may have, and the scan buffer size leaves no room for segments";
+    return HG_ERR_NOMEM;
+  }
+  fin_fallback_ = false;  // (a smaller stretch: bucketed emission gets another chance)
+  fin_expect_hits_ /= nsegments;
+  uint64_t acc = 0, cands = 0, raw = 0, cs0 = 0, piece0 = line_base;
+  uint32_t reruns = 0, launches = 0;
+  float ms_stream = 0, ms_total = 0;
+  HgScanOutput part{};
+  for (uint64_t lo = 0; lo < ntiles; lo += seg_tiles) {
+    const bool last = lo + seg_tiles >= ntiles;
+    const PassRange range{lo, last ? ntiles : std::min<uint64_t>(ntiles, lo + seg_tiles + reach), cs0, piece0, lo << HG_TILE_SHIFT, last ? ~0ull : (lo + seg_tiles) << HG_TILE_SHIFT, last};
+    for (uint32_t tries = 0;; tries++) {
+      bool overflow = false;
+      std::memset(&part, 0, sizeof part);
+      const int rc = run_once(text, nbytes, bs1, line_base, range, false, stream, &part, &overflow);
+      if (rc == HG_SPLIT) {
+        *too_many = true;
+        return HG_OK;
+      }
+      if (rc) return rc;
+      if (!overflow) break;
+      reruns++;
+      if (tries > 16) {
+        err_ = "workspace kept overflowing";
+        return HG_ERR_NOMEM;
+      }
+    }
+    // this pass's ordered hits behind those of the earlier segments
+    if (acc + part.n_hits > acc_cap_) {
+      // sized from the hits so far, the share of the text they came from, and a quarter on top
+      const uint64_t done = std::max<uint64_t>(std::min<uint64_t>(ntiles, lo + seg_tiles), 1);
+      const uint64_t guess = static_cast<uint64_t>(static_cast<double>(acc + part.n_hits) * static_cast<double>(ntiles) / static_cast<double>(done) * 1.25) + 4096;
+      const uint64_t cap = std::max<uint64_t>(acc + part.n_hits, guess);
+      HgHit *nh = nullptr;
+      HgHitAux *na = nullptr;
+      if (fail(hgmem::dev_alloc(&nh, cap * sizeof(HgHit), "d_acc_hits_"), "alloc (segment hits)") || fail(hgmem::dev_alloc(&na, cap * sizeof(HgHitAux), "d_acc_aux_"), "alloc (segment hits)")) {
+        hgmem::dev_free(nh, "d_acc_hits_");
+        return HG_ERR_HIP;
+      }
+      if (acc) {
+        if (fail(hipMemcpyAsync(nh, d_acc_hits_, acc * sizeof(HgHit), hipMemcpyDeviceToDevice, stream), "copy") ||
+            fail(hipMemcpyAsync(na, d_acc_aux_, acc * sizeof(HgHitAux), hipMemcpyDeviceToDevice, stream), "copy") || fail(hipStreamSynchronize(stream), "sync"))
+          return HG_ERR_HIP;
+      }
+      hgmem::dev_free(d_acc_hits_, "d_acc_hits_");
+      hgmem::dev_free(d_acc_aux_, "d_acc_aux_");
+      d_acc_hits_ = nh;
+      d_acc_aux_ = na;
+      acc_cap_ = cap;
+    }
+    if (part.n_hits) {
+      if (fail(hipMemcpyAsync(d_acc_hits_ + acc, part.d_hits, part.n_hits * sizeof(HgHit), hipMemcpyDeviceToDevice, stream), "copy") ||
+          fail(hipMemcpyAsync(d_acc_aux_ + acc, part.d_aux, part.n_hits * sizeof(HgHitAux), hipMemcpyDeviceToDevice, stream), "copy"))
+        return HG_ERR_HIP;
+    }
+    acc += part.n_hits;
+    cands += part.n_cands;
+    raw += part.n_raw_hits;
+    ms_stream += part.ms_stream;
+    ms_total += part.ms_total;
+    launches += part.stream_launches;
+    if (!last) {  // the tile-scan state at the next segment's first tile (this pass has scanned past it)
+      HgTileBase next{};
+      if (fail(hipMemcpyAsync(&next, d_bases_ + (lo + seg_tiles), sizeof next, hipMemcpyDeviceToHost, stream), "copy") || fail(hipStreamSynchronize(stream), "sync")) return HG_ERR_HIP;
+      cs0 = next.cs;
+      piece0 = next.L;
+    }
+  }
+  if (fail(hipStreamSynchronize(stream), "sync")) return HG_ERR_HIP;
+  out->n_hits = acc;
+  out->n_pieces = part.n_pieces;
+  out->n_cands = cands;
+  out->n_raw_hits = raw;
+  out->d_hits = d_acc_hits_;
+  out->d_aux = d_acc_aux_;
+  out->ms_stream = ms_stream;
+  out->ms_total = ms_total;
+  out->reruns = reruns;
+  out->stream_launches = launches;
   return HG_OK;
 }

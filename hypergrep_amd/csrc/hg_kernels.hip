@@ -785,14 +785,16 @@ struct HitSink {
   // fields are read from the kernel arguments at the call, not kept here: a larger struct went through scratch.)
   __device__ __forceinline__ void push(const HgConfirmArgs &a, uint64_t line_no, uint32_t id, uint32_t to, uint64_t start, uint32_t len, uint32_t pattern,
                                        bool single) const {
+    if (start < a.own_lo || start >= a.own_hi) return;  // (segmented scans: the piece is another segment's to report)
     if (a.bucket_cap) {  // straight into the bucket of the line's start; the finalize kernels order each bucket
-      const uint32_t b = static_cast<uint32_t>(start >> a.bucket_shift);
+      const uint64_t rel_start = start - a.own_lo;
+      const uint32_t b = static_cast<uint32_t>(rel_start >> a.bucket_shift);
       const uint32_t slot = atomicAdd(&a.bucket_fill[b], 1u);
       if (slot < a.bucket_cap) {
         const uint64_t at = static_cast<uint64_t>(b) * a.bucket_cap + slot;
         // raw record: the line's start inside its bucket rides in the top bits of the line number — it orders the bucket's
         // lines like the line number does, in far fewer key bits (hg_fin_*; the gather strips both extras again)
-        const uint64_t rel = start & ((1ull << a.bucket_shift) - 1ull);
+        const uint64_t rel = rel_start & ((1ull << a.bucket_shift) - 1ull);
         a.hits[at] = HgHit{line_no | (rel << HG_HIT_REL_SHIFT), id, to | (single ? HG_HIT_SINGLE_BIT : 0u)};
         a.aux[at] = HgHitAux{start, len, pattern};
       } else {
@@ -806,6 +808,7 @@ struct HitSink {
       seg_aux[slot] = HgHitAux{start, len, pattern};
     } else if (a.hit_direct) {
       const uint32_t at = atomicAdd(&a.counters[HG_CNT_HITS], 1u);
+      if (at == 0xFFFFFFFFu) a.counters[HG_CNT_HITS_WRAPPED] = 1u;
       if (at < a.hit_cap) {
         a.hits[at] = HgHit{line_no, id, to};
         a.aux[at] = HgHitAux{start, len, pattern};
@@ -1877,15 +1880,16 @@ __global__ __launch_bounds__(256) void hg_block_small_kernel(HgDbView db, const 
 // ------------------------------------------------------------------------------------------------
 // One launch puts the scanner's device state in place for a pass (it used to be half a dozen memsets and a host-to-device
 // copy, each a launch of its own in front of the first stream kernel): counters, tile cursors, finalize totals and flags
-// zeroed, the tile-scan state set to (carry-in line start 0, first line number), bucket fill levels and the
+// zeroed, the tile-scan state set to (carry-in line start, first line number: 0 and the caller's base for a whole
+// buffer, the state at the segment's first tile for a segment of one), bucket fill levels and the
 // verified-occurrence counts zeroed.
-__global__ void hg_reset_kernel(uint32_t *state, uint32_t state_words, HgTileBase *final_state, uint64_t line_base, uint32_t *fill, uint32_t nb, uint32_t *defer_count,
-                                uint32_t ndefer) {
+__global__ void hg_reset_kernel(uint32_t *state, uint32_t state_words, HgTileBase *final_state, uint64_t carry_start, uint64_t first_piece, uint32_t *fill, uint32_t nb,
+                                uint32_t *defer_count, uint32_t ndefer) {
   const uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
   for (uint32_t i = i0; i < state_words; i += stride) state[i] = 0;
   for (uint32_t i = i0; i < nb; i += stride) fill[i] = 0;
   for (uint32_t i = i0; i < ndefer; i += stride) defer_count[i] = 0;
-  if (i0 == 0) *final_state = HgTileBase{0, line_base};
+  if (i0 == 0) *final_state = HgTileBase{carry_start, first_piece};
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -453,6 +453,13 @@ def test_chunked_pipeline_matches_oracle(torch_cuda, monkeypatch):
     stats = sc.scan(text.data_ptr(), nbytes)
     assert stats.n_lines == nlines
     assert sorted(sc.hits()) == want and len(want) > 1000
+    # the same text in two segments of two pipeline chunks each (a pass may hold fewer reports than the text has)
+    monkeypatch.setenv("HG_HIT_LIMIT", str(int(stats.n_raw_hits * 0.6)))
+    sc_seg = device.Scanner(db, 0)
+    st_seg = sc_seg.scan(text.data_ptr(), nbytes)
+    assert st_seg.n_lines == nlines and st_seg.stream_launches >= 4
+    assert sc_seg.hits() == want
+    monkeypatch.delenv("HG_HIT_LIMIT")
     # and again with a pattern from the always-on tier in the mix
     pats2 = patterns + ["warn|retry"]
     want2, _ = oracle_hits(host[: 20 << 20], pats2, ids=ids + [999])
@@ -1099,6 +1106,43 @@ def test_always_on_groups_with_boundary_conditions(torch_cuda, monkeypatch):
         want, nlines = oracle_hits(data, p, f, i)
         got, stats = gpu_scan_buffer(torch_cuda, data, p, f, i)
         assert got == want and stats.n_lines == nlines, sub
+
+
+def test_scan_in_segments(torch_cuda, monkeypatch):
+    """More reports than one pass may hold (2^28; lowered here): the buffer is scanned in 2, 4, 8 ... segments, each pass
+    reporting the pieces that start in its stretch and scanning on as far as such a piece reaches; the segments' ordered
+    hits are put one after the other.  Lines longer than the scan buffer (pieces) across segment boundaries, NUL bytes,
+    always-on and prefiltered expressions, SINGLEMATCH and all-matches reports, a line base: equal to the oracle, in order."""
+    from hypergrep_amd import device
+
+    rng = random.Random(4242)
+    pats = ["needle_in_haystack", "fo+bar[0-9]*", "a.c", "\\bGET\\b", "=7", "st.*us=2", "[0-9]+\\.[0-9]+", "(?i)error.*timeout"]
+    flags = [14, 14, 6, 10, 14, 14, 6, 14]
+    ids = [0, 1, 2, 3, 3, 4, 5, 1]
+    parts = []
+    for k in range(12):  # ~6 MiB: ordinary lines, and every 512 KiB or so a line of 300 000 bytes (two pieces at the default scan buffer)
+        parts.append(regex_gen.random_text(rng, 4500, maxlen=200))
+        parts.append(b"status=200 GET /a.c " + b"q" * 150000 + b" needle_in_haystack foobar7 abc =7 " + b"z" * 150000 + b" 3.14 ERROR x timeout\n")
+    data = b"".join(parts)
+    data = data[:700000] + b"\0" + data[700001:2000000] + b"\0\0" + data[2000002:]
+    for bs, limit in ((262140, 6000), (3000, 2500), (262140, 40000)):
+        want, nlines = oracle_hits(data, pats, flags, ids, buffer_size=bs)
+        monkeypatch.setenv("HG_HIT_LIMIT", str(limit))
+        n = len(data)
+        buf = torch_cuda.zeros(n + 32, dtype=torch_cuda.uint8, device="cuda:0")
+        buf[:n] = torch_cuda.frombuffer(bytearray(data), dtype=torch_cuda.uint8).cuda()
+        torch_cuda.cuda.synchronize()
+        sc = device.Scanner(device.Database(pats, flags=flags, ids=ids), 0)
+        stats = sc.scan(buf.data_ptr(), n, buffer_size=bs, line_base=5)
+        got = sc.hits()
+        assert stats.n_lines == nlines and stats.stream_launches >= 2, (bs, limit, stats)
+        assert got == sorted(got)
+        assert [(ln - 5, i, to, st, le) for ln, i, to, st, le in got] == want, (bs, limit)
+        assert len(want) > limit
+        monkeypatch.delenv("HG_HIT_LIMIT")
+        # and the scanner is as good as new for an ordinary pass
+        st2 = sc.scan(buf.data_ptr(), n, buffer_size=bs)
+        assert sorted(sc.hits()) == want and st2.n_lines == nlines
 
 
 def test_dense_candidates_shrink_the_pipeline_chunks(torch_cuda, monkeypatch):
