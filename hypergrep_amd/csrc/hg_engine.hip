@@ -297,7 +297,9 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   }
   if (!block_mode && chunk_limit_tiles_ && chunk_tiles > chunk_limit_tiles_) chunk_tiles = chunk_limit_tiles_;  // (a chunk's candidates did not fit before)
   nchunks = ntiles ? static_cast<uint32_t>((ntiles + chunk_tiles - 1) / chunk_tiles) : 1;
-  if (nchunks > static_cast<uint32_t>(kMaxChunks)) return HG_SPLIT;  // (chunks that shrank for a dense text: fewer tiles per pass then)
+  uint32_t max_chunks = static_cast<uint32_t>(kMaxChunks);
+  if (const char *env = std::getenv("HG_MAX_CHUNKS")) max_chunks = static_cast<uint32_t>(std::max(1l, std::min<long>(kMaxChunks, std::strtol(env, nullptr, 10))));  // (tests)
+  if (nchunks > max_chunks) return HG_SPLIT;  // (chunks that shrank for a dense text: fewer tiles per pass then)
   std::vector<uint64_t> cut(nchunks + 1);  // chunk c = tiles [cut[c], cut[c + 1])
   for (uint32_t c = 0; c <= nchunks; c++) cut[c] = std::min<uint64_t>(tile_lo + static_cast<uint64_t>(c) * chunk_tiles, tile_hi);
   if (const char *env = std::getenv("HG_CHUNK_WEIGHTS")) {  // experiment: relative chunk sizes, e.g. "10,10,8,4"

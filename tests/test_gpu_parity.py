@@ -460,6 +460,13 @@ def test_chunked_pipeline_matches_oracle(torch_cuda, monkeypatch):
     assert st_seg.n_lines == nlines and st_seg.stream_launches >= 4
     assert sc_seg.hits() == want
     monkeypatch.delenv("HG_HIT_LIMIT")
+    # ... and when the text needs more pipeline chunks than a pass has (64; lowered here to 2)
+    monkeypatch.setenv("HG_MAX_CHUNKS", "2")
+    sc_seg2 = device.Scanner(db, 0)
+    st_seg2 = sc_seg2.scan(text.data_ptr(), nbytes)
+    assert st_seg2.n_lines == nlines and st_seg2.stream_launches >= 4
+    assert sc_seg2.hits() == want
+    monkeypatch.delenv("HG_MAX_CHUNKS")
     # and again with a pattern from the always-on tier in the mix
     pats2 = patterns + ["warn|retry"]
     want2, _ = oracle_hits(host[: 20 << 20], pats2, ids=ids + [999])
