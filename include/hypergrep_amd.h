@@ -176,7 +176,8 @@ const char *hg_scanner_error(const hg_scanner_t *scanner);
 
 /* Scan `nbytes` of text resident in HBM at d_text (16-byte aligned; must be readable up to nbytes
  * rounded up to 16).  Lines are numbered from line_base.  `stream` is a hipStream_t (NULL = default).
- * Blocks until the results are ready. */
+ * Blocks until the results are ready.  No size limit besides HBM: a buffer with more than 2^28 reports (or more
+ * pipeline chunks than one pass has) is scanned in segments whose ordered hits are put one after the other. */
 int hg_scan_device(hg_scanner_t *scanner, const void *d_text, uint64_t nbytes, int buffer_size,
                    uint64_t line_base, void *stream, hg_scan_result_t *result);
 
