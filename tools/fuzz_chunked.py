@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomized property run on the GPU: the chunked two-stream pipeline must deliver exactly the records of the single
+"""Randomized property run on the GPU: the chunked two-stream pipeline and the segmented scan must deliver exactly the records of the single
 pass — random pattern sets (dword-aligned, byte-aligned, always-on, mixed), sizes, chunk sizes, scan buffers, line bases.
     python tools/fuzz_chunked.py [seconds] [first seed]"""
 import os
@@ -66,6 +66,25 @@ while time.time() - t0 < budget:
     one, a = run()
     os.environ["HG_CHUNK_TILES"] = str(chunk_tiles)
     many, b = run()
+    # ... and in segments (a pass may hold fewer reports / pipeline chunks than the text needs)
+    seg_same = True
+    if one.n_raw_hits >= 8192 and rng.random() < 0.7:
+        how = rng.choice(["hits", "chunks", "both"])
+        if how in ("hits", "both"):
+            os.environ["HG_HIT_LIMIT"] = str(max(1024, one.n_raw_hits // rng.choice([2, 3, 7])))
+        if how in ("chunks", "both"):
+            os.environ["HG_MAX_CHUNKS"] = str(rng.choice([1, 2]))
+        try:
+            seg, c = run()
+            seg_same = (one.n_hits, one.n_lines) == (seg.n_hits, seg.n_lines) and bool((a == c).all()) and seg.stream_launches >= 2
+        except Exception as e:
+            seg_same = False
+            print(f"seed {seed - 1}: segmented scan: {e}", flush=True)
+        os.environ.pop("HG_HIT_LIMIT", None)
+        os.environ.pop("HG_MAX_CHUNKS", None)
+        if not seg_same:
+            fails += 1
+            print(f"SEGMENT MISMATCH seed {seed - 1} kind={kind} how={how} bytes={nbytes} bs={bs} chunk_tiles={chunk_tiles} raw={one.n_raw_hits} pats={pats[:6]}", flush=True)
     cases += 1
     same = (one.n_hits, one.n_lines) == (many.n_hits, many.n_lines) and bool((a == b).all())
     if not same or many.stream_launches < 2:
