@@ -743,7 +743,12 @@ struct Info {
   LitSet set;
   bool has_cover = false;  // every match contains one of `cover`
   LitSet cover;
+  long lead = 0;  // ... beginning at most this many bytes after the match's start (-1: no bound); the confirm window's size
 };
+long add_len(long a, long b) {  // lengths with -1 = unbounded
+  if (a < 0 || b < 0 || a + b > (1 << 20)) return -1;
+  return a + b;
+}
 
 int byte_commonness(unsigned char b) {
   if (b == ' ') return 10;
@@ -770,11 +775,12 @@ bool better_cover(const LitSet &a, const LitSet &b) {
   if (a.size() != b.size()) return a.size() < b.size();
   return min_len(a) > min_len(b);
 }
-void offer(Info &info, const LitSet &cand) {
+void offer(Info &info, const LitSet &cand, long lead) {
   if (cand.empty() || min_len(cand) == 0 || cand.size() > MAX_EXACT) return;
   if (!info.has_cover || better_cover(cand, info.cover)) {
     info.has_cover = true;
     info.cover = cand;
+    info.lead = lead;
   }
 }
 bool cross(const LitSet &a, const LitSet &b, LitSet &out) {
@@ -816,43 +822,59 @@ Info analyze(const Node &n) {
     case Node::Cat: {
       LitSet run{{"", ""}};
       bool all_exact = true;
+      long before = 0;    // the most bytes the kids before the current one can match
+      long run_lead = 0;  // ... before the first kid of the current run of exact kids
       auto flush = [&]() {
-        offer(r, run);
+        offer(r, run, run_lead);
         run = LitSet{{"", ""}};
       };
       for (auto &k : n.kids) {
         Info ki = analyze(*k);
-        if (ki.has_cover) offer(r, ki.cover);
+        const long after = add_len(before, max_match_len(*k));
+        if (ki.has_cover) offer(r, ki.cover, add_len(before, ki.lead));
         if (ki.exact) {
           LitSet next;
           if (cross(run, ki.set, next)) run = std::move(next);
-          else { all_exact = false; flush(); run = ki.set; if (run.size() > MAX_EXACT) run = LitSet{{"", ""}}; }
+          else {
+            all_exact = false;
+            flush();
+            run = ki.set;
+            run_lead = before;  // the new run begins with this kid
+            if (run.size() > MAX_EXACT) { run = LitSet{{"", ""}}; run_lead = after; }
+          }
         } else {
           all_exact = false;
           flush();
+          run_lead = after;  // the next run begins behind this kid
         }
+        before = after;
       }
       if (all_exact) { r.exact = true; r.set = run; }
-      offer(r, run);
+      offer(r, run, run_lead);
       return r;
     }
     case Node::Alt: {
       bool all_exact = true, all_cover = true;
       LitSet uni, cov;
+      long cov_lead = 0;  // the largest lead among the branches' covers (a branch's whole literal set begins with the match: 0)
       for (auto &k : n.kids) {
         Info ki = analyze(*k);
         if (ki.exact) { uni.insert(uni.end(), ki.set.begin(), ki.set.end()); }
         else all_exact = false;
         const LitSet *c = ki.has_cover ? &ki.cover : (ki.exact && min_len(ki.set) > 0 ? &ki.set : nullptr);
         if (ki.exact && ki.has_cover && min_len(ki.set) > 0 && better_cover(ki.set, ki.cover)) c = &ki.set;
-        if (c) cov.insert(cov.end(), c->begin(), c->end());
+        if (c) {
+          cov.insert(cov.end(), c->begin(), c->end());
+          const long l = c == &ki.cover ? ki.lead : 0;
+          cov_lead = (cov_lead < 0 || l < 0) ? -1 : std::max(cov_lead, l);
+        }
         else all_cover = false;
       }
       dedupe(uni);
       dedupe(cov);
       if (all_exact && uni.size() <= MAX_EXACT) { r.exact = true; r.set = uni; }
-      if (all_cover) offer(r, cov);
-      if (r.exact) offer(r, r.set);
+      if (all_cover) offer(r, cov, cov_lead);
+      if (r.exact) offer(r, r.set, 0);
       return r;
     }
     case Node::Rep: {
@@ -865,10 +887,10 @@ Info analyze(const Node &n) {
           ok = cross(acc, ki.set, next);
           if (ok) acc = std::move(next);
         }
-        if (ok) { r.exact = true; r.set = acc; offer(r, acc); return r; }
+        if (ok) { r.exact = true; r.set = acc; offer(r, acc, 0); return r; }
       }
       if (n.min >= 1) {
-        if (ki.has_cover) offer(r, ki.cover);
+        if (ki.has_cover) offer(r, ki.cover, ki.lead);  // (the occurrence inside the FIRST copy)
         if (ki.exact) {  // at least `min` consecutive copies are required
           LitSet acc{{"", ""}};
           for (int i = 0; i < std::min(n.min, 32); i++) {
@@ -876,7 +898,7 @@ Info analyze(const Node &n) {
             if (!cross(acc, ki.set, next)) break;
             acc = std::move(next);
           }
-          offer(r, acc);
+          offer(r, acc, 0);
         }
       }
       return r;
@@ -886,7 +908,8 @@ Info analyze(const Node &n) {
 }
 
 // Keep at most HG_FACTOR_MAX bytes of a long literal: the sub-run whose rarest window is rarest.
-Lit clip(const Lit &l) {
+Lit clip(const Lit &l, size_t *offset = nullptr) {
+  if (offset) *offset = 0;
   if (l.bytes.size() <= HG_FACTOR_MAX) return l;
   size_t best = 0;
   int best_score = INT32_MAX;
@@ -895,6 +918,7 @@ Lit clip(const Lit &l) {
     for (size_t i = 0; i < HG_FACTOR_MAX; i++) s += byte_commonness(static_cast<unsigned char>(l.bytes[o + i]));
     if (s < best_score) { best_score = s; best = o; }
   }
+  if (offset) *offset = best;
   return {l.bytes.substr(best, HG_FACTOR_MAX), l.cmask.substr(best, HG_FACTOR_MAX)};
 }
 
@@ -1406,9 +1430,16 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
       // required literals
       Info info = analyze(*root);
       LitSet cover;
-      if (info.has_cover) for (auto &l : info.cover) cover.push_back(clip(l));
+      long lead = info.lead;  // (a literal cut down to HG_FACTOR_MAX bytes begins that much later)
+      if (info.has_cover)
+        for (auto &l : info.cover) {
+          size_t cut = 0;
+          cover.push_back(clip(l, &cut));
+          if (cut) lead = add_len(lead, static_cast<long>(cut));
+        }
       dedupe(cover);
       covers[cur].lits = cover;
+      p.lit_lead = (info.has_cover && lead >= 0 && !std::getenv("HG_NO_CONFIRM_WINDOW")) ? static_cast<uint32_t>(lead) : 0xFFFFFFFFu;
       // literal-only: the expression's language is exactly one literal that fits the factor record, has no NUL
       // or inner newline, and no assertions -> a verified factor occurrence is a match
       if (info.exact && info.set.size() == 1 && cover.size() == 1 && info.set[0].bytes.size() <= HG_FACTOR_MAX &&

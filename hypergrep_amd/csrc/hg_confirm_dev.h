@@ -189,34 +189,61 @@ __device__ __forceinline__ void confirm_literal(const uint8_t *text, uint64_t nb
   emit(pv.line_no, static_cast<uint32_t>(from - a), a, static_cast<uint32_t>(z - a));
 }
 
+// The automaton confirm routines work on a WINDOW of the line, not on the line.
+// A SINGLEMATCH expression reports the smallest match end of its line.  Every match contains an occurrence of the
+// expression's required literal at most `lead` bytes after the match's start (hg_compile.cpp: Info::lead; 0xFFFFFFFF =
+// no bound), every such occurrence is a candidate of its own, and the finalize keeps the smallest end per (line, id).  So
+// the candidate whose verified occurrence starts at `fs` only has to answer for the matches that START in
+// [fs - lead, fs]: the automaton starts at max(first scanned byte, fs - lead) with the left context read from the text,
+// start states are injected up to fs, and the run ends at the first accept or as soon as no state is alive past fs.
+// A wave's 64 lanes then run for a literal's length plus a few bytes each, instead of for their whole lines (the lanes
+// wait for the longest one: per-wave timing put a batch at 90-350 us, tools/confirm_waves.py).
+struct MatchWindow {
+  uint64_t line_no, a, limit, q;  // piece index, first scanned byte of the piece, end of the piece's buffer, first byte the automaton sees
+  uint32_t pc;                    // context left of q
+};
+__device__ __forceinline__ bool match_window(const uint8_t *text, uint64_t nbytes, const HgTileSum *sums, const HgTileBase *bases, uint64_t bs1, uint64_t pos,
+                                             uint32_t rank, uint64_t fs, uint32_t lead, MatchWindow *w) {
+  PieceView pv;
+  if (!piece_view(text, nbytes, sums, bases, bs1, pos, rank, pos, &pv)) return false;  // (a NUL between the first scanned byte and pos: pos is not scanned)
+  if (!pv.whole) {  // a later piece of an over-long line (rare): the NUL rule byte by byte
+    if (pv.a > pos) return false;
+    for (uint64_t i = pv.a; i < pos; i++)
+      if (text[i] == 0) return false;
+  }
+  if (fs < pv.a) return false;  // the occurrence begins before the scanned bytes: no match inside them contains it
+  w->line_no = pv.line_no;
+  w->a = pv.a;
+  w->limit = pv.limit;
+  w->q = (lead != 0xFFFFFFFFu && fs - pv.a > lead) ? fs - lead : pv.a;
+  w->pc = w->q == pv.a ? static_cast<uint32_t>(HG_PC_START) : hg_prev_ctx(text[w->q - 1]);  // (a scanned byte: neither NUL nor newline)
+  return true;
+}
+// end of the scanned bytes given a match that ends at e (> a): just past a newline that is its last byte, else the first
+// NUL / just past the first newline from e on
+__device__ __forceinline__ uint64_t window_scanned_end(const uint8_t *text, uint64_t e, uint64_t limit) {
+  return text[e - 1] == '\n' ? e : scanned_end(text, e, limit);
+}
+
 // Confirm one (candidate, pattern) for a "simple" SINGLEMATCH pattern (one state word, no boundary conditions).  reach[256] /
 // follow[nodes]: the pattern's tables, staged by the wave in LDS (no table traffic to HBM / L2; the 16 reach lookups of a chunk
-// are independent).  Reports at most one hit: the smallest match end offset.
+// are independent).  Reports at most one hit: the smallest end of a match that starts in the window.
 template <typename Emit>
 __device__ __forceinline__ void confirm_simple(const uint8_t *text, uint64_t nbytes, const HgTileSum *sums, const HgTileBase *bases, uint64_t bs1, uint64_t pos,
-                                                   uint32_t rank, uint32_t init, uint32_t acc, const lds_u32 *reach, const lds_u32 *follow, Emit &&emit) {
-  const uint64_t t = pos >> HG_TILE_SHIFT, tile_start = t << HG_TILE_SHIFT;
-  const uint64_t s = rank == 0 ? bases[t].cs : line_start_in_tile(text, tile_start, pos);
-  const uint64_t k = (pos - s) / bs1;
-  const uint64_t ps = s + k * bs1;
-  const uint64_t line_no = hg_line_index(text, sums[t], bases[t], tile_start, rank, s, bs1, bs1 < HG_TILE_BYTES) + k;
-  const uint64_t limit = ps + bs1 < nbytes ? ps + bs1 : nbytes;
-
-
-  // leading NULs are skipped (hyperscanner.c:207-214): a = first non-NUL byte of the piece
-  uint64_t a = ps;
-  while (a < limit && text[a] == 0) a++;
-  if (a >= limit) return;  // empty or all-NUL piece
-
+                                                   uint32_t rank, uint64_t fs, uint32_t lead, uint32_t init, uint32_t acc, const lds_u32 *reach, const lds_u32 *follow,
+                                                   Emit &&emit) {
+  MatchWindow w;
+  if (!match_window(text, nbytes, sums, bases, bs1, pos, rank, fs, lead, &w)) return;
+  const uint64_t a = w.a, limit = w.limit, q = w.q;
   uint32_t S = 0, first_to = HG_NONE32;
-  uint64_t z = limit;
-  for (uint64_t chunk = a & ~15ull; chunk < limit; chunk += 16) {
+  bool alive = true;
+  for (uint64_t chunk = q & ~15ull; chunk < limit && alive; chunk += 16) {
     const uint4 v = *reinterpret_cast<const uint4 *>(text + chunk);
-    const uint32_t lo = chunk < a ? static_cast<uint32_t>(a - chunk) : 0u;
+    const uint32_t lo = chunk < q ? static_cast<uint32_t>(q - chunk) : 0u;
     const uint32_t hi = limit - chunk < 16 ? static_cast<uint32_t>(limit - chunk) : 16u;
     const uint32_t below_lo = (1u << lo) - 1u;
     const uint32_t nl = eq_mask16(v, 0x0a0a0a0au) & ~below_lo, nul = eq_mask16(v, 0u) & ~below_lo;
-    // bytes [lo, end) of this chunk belong to the scanned line; the piece ends inside the chunk if stop
+    // bytes [lo, end) of this chunk belong to the scanned bytes; they end inside the chunk if stop
     uint32_t end = hi;
     bool stop = false;
     const uint32_t stops = (nl | nul) & ((1u << hi) - 1u);
@@ -225,55 +252,50 @@ __device__ __forceinline__ void confirm_simple(const uint8_t *text, uint64_t nby
       end = ((nl >> e) & 1u) ? e + 1 : e;  // a newline is part of the line, a NUL is not
       stop = true;
     }
-    if (first_to == HG_NONE32) {
-      uint32_t r[16];
+    uint32_t r[16];
 #pragma unroll
-      for (int i = 0; i < 16; i++) r[i] = reach[byte_of(v, i)];  // 16 independent loads
+    for (int i = 0; i < 16; i++) r[i] = reach[byte_of(v, i)];  // 16 independent loads
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        if (static_cast<uint32_t>(i) >= lo && static_cast<uint32_t>(i) < end && first_to == HG_NONE32) {
-          uint32_t T = init;
-          for (uint32_t x = S; x; x &= x - 1) T |= follow[__ffs(x) - 1];
-          S = T & r[i];
-          if (S & acc) first_to = static_cast<uint32_t>(chunk + i + 1 - a);
+    for (int i = 0; i < 16; i++) {
+      if (static_cast<uint32_t>(i) >= lo && static_cast<uint32_t>(i) < end && alive) {
+        const uint64_t at = chunk + i;
+        uint32_t T = at <= fs ? init : 0u;  // matches that start after fs belong to later occurrences
+        for (uint32_t x = S; x; x &= x - 1) T |= follow[__ffs(x) - 1];
+        S = T & r[i];
+        if (S & acc) {
+          first_to = static_cast<uint32_t>(at + 1 - a);
+          alive = false;
+        } else if (S == 0 && at >= fs) {
+          alive = false;  // nothing alive and no start left
         }
       }
     }
-    if (stop || hi < 16) {
-      z = chunk + end;
-      break;
-    }
+    if (stop || hi < 16) break;
   }
-  if (first_to != HG_NONE32) emit(line_no, first_to, a, static_cast<uint32_t>(z - a));
+  if (first_to != HG_NONE32) {
+    const uint64_t z = window_scanned_end(text, a + first_to, limit);
+    emit(w.line_no, first_to, a, static_cast<uint32_t>(z - a));
+  }
 }
 
 // Confirm one (candidate, pattern) for a SINGLEMATCH pattern with up to NW <= 2 state words and arbitrary boundary
-// conditions (^ $ \b ...): same chunked walk as confirm_simple, automaton tables read from HBM/L2 (the handful of
-// 4-byte lookups per text byte depend on the text only, except follow[], so they pipeline).
+// conditions (^ $ \b ...): the same windowed run, with the per-context entry / accept tables.
 template <int NW, typename Emit>
 __device__ __forceinline__ void confirm_ctx(const uint8_t *text, uint64_t nbytes, const HgTileSum *sums, const HgTileBase *bases, uint64_t bs1, uint64_t pos,
-                                                uint32_t rank, const lds_u32 *reach, const lds_u32 *follow, const lds_u32 *init, const lds_u32 *amask, const lds_u32 *acct,
-                                                Emit &&emit) {
-  const uint64_t t = pos >> HG_TILE_SHIFT, tile_start = t << HG_TILE_SHIFT;
-  const uint64_t s = rank == 0 ? bases[t].cs : line_start_in_tile(text, tile_start, pos);
-  const uint64_t k = (pos - s) / bs1;
-  const uint64_t ps = s + k * bs1;
-  const uint64_t line_no = hg_line_index(text, sums[t], bases[t], tile_start, rank, s, bs1, bs1 < HG_TILE_BYTES) + k;
-  const uint64_t limit = ps + bs1 < nbytes ? ps + bs1 : nbytes;
-
-
-  uint64_t a = ps;
-  while (a < limit && text[a] == 0) a++;
-  if (a >= limit) return;
-
+                                                uint32_t rank, uint64_t fs, uint32_t lead, const lds_u32 *reach, const lds_u32 *follow, const lds_u32 *init,
+                                                const lds_u32 *amask, const lds_u32 *acct, Emit &&emit) {
+  MatchWindow w;
+  if (!match_window(text, nbytes, sums, bases, bs1, pos, rank, fs, lead, &w)) return;
+  const uint64_t a = w.a, limit = w.limit, q = w.q;
   uint32_t S[NW], I[NW];
 #pragma unroll
-  for (int w = 0; w < NW; w++) { S[w] = 0; I[w] = init[w]; }
-  uint32_t pc = HG_PC_START, first_to = HG_NONE32;
-  uint64_t z = limit;
-  for (uint64_t chunk = a & ~15ull; chunk < limit; chunk += 16) {
+  for (int u = 0; u < NW; u++) { S[u] = 0; I[u] = init[u]; }
+  uint32_t pc = w.pc, first_to = HG_NONE32;
+  bool alive = true;
+  uint64_t z = limit;  // end of the scanned bytes, once the walk has reached it
+  for (uint64_t chunk = q & ~15ull; chunk < limit && alive; chunk += 16) {
     const uint4 v = *reinterpret_cast<const uint4 *>(text + chunk);
-    const uint32_t lo = chunk < a ? static_cast<uint32_t>(a - chunk) : 0u;
+    const uint32_t lo = chunk < q ? static_cast<uint32_t>(q - chunk) : 0u;
     const uint32_t hi = limit - chunk < 16 ? static_cast<uint32_t>(limit - chunk) : 16u;
     const uint32_t below_lo = (1u << lo) - 1u;
     const uint32_t nl = eq_mask16(v, 0x0a0a0a0au) & ~below_lo, nul = eq_mask16(v, 0u) & ~below_lo;
@@ -285,34 +307,36 @@ __device__ __forceinline__ void confirm_ctx(const uint8_t *text, uint64_t nbytes
       end = ((nl >> e) & 1u) ? e + 1 : e;
       stop = true;
     }
-    if (first_to == HG_NONE32) {
 #pragma unroll
-      for (int i = 0; i < 16; i++) {
-        if (static_cast<uint32_t>(i) >= lo && static_cast<uint32_t>(i) < end && first_to == HG_NONE32) {
-          const uint32_t c = byte_of(v, i);
-          // inside one line a '\n' is always the last scanned byte
-          const uint32_t cc = c == '\n' ? HG_NC_NLFINAL : (hg_is_word(c) ? HG_NC_WORD : HG_NC_OTHER);
-          const lds_u32 *ac = acct + (pc * 5 + cc) * NW, *am = amask + (pc * 4 + cc) * NW, *rc = reach + c * NW;
-          uint32_t hit = 0;
+    for (int i = 0; i < 16; i++) {
+      if (static_cast<uint32_t>(i) >= lo && static_cast<uint32_t>(i) < end && alive) {
+        const uint64_t at = chunk + i;
+        const uint32_t c = byte_of(v, i);
+        // inside one line a '\n' is always the last scanned byte
+        const uint32_t cc = c == '\n' ? HG_NC_NLFINAL : (hg_is_word(c) ? HG_NC_WORD : HG_NC_OTHER);
+        const lds_u32 *ac = acct + (pc * 5 + cc) * NW, *am = amask + (pc * 4 + cc) * NW, *rc = reach + c * NW;
+        uint32_t hit = 0;
 #pragma unroll
-          for (int w = 0; w < NW; w++) hit |= S[w] & ac[w];
-          if (hit) {
-            first_to = static_cast<uint32_t>(chunk + i - a);
-          } else {
-            uint32_t T[NW];
+        for (int u = 0; u < NW; u++) hit |= S[u] & ac[u];
+        if (hit) {  // a match ends before this byte
+          first_to = static_cast<uint32_t>(at - a);
+          alive = false;
+        } else {
+          uint32_t T[NW];
 #pragma unroll
-            for (int w = 0; w < NW; w++) T[w] = I[w];
+          for (int u = 0; u < NW; u++) T[u] = at <= fs ? I[u] : 0u;  // matches that start after fs belong to later occurrences
 #pragma unroll
-            for (int w = 0; w < NW; w++)
-              for (uint32_t x = S[w]; x; x &= x - 1) {
-                const lds_u32 *f = follow + (w * 32 + (__ffs(x) - 1)) * NW;
+          for (int u = 0; u < NW; u++)
+            for (uint32_t x = S[u]; x; x &= x - 1) {
+              const lds_u32 *f = follow + (u * 32 + (__ffs(x) - 1)) * NW;
 #pragma unroll
-                for (int q = 0; q < NW; q++) T[q] |= f[q];
-              }
+              for (int k = 0; k < NW; k++) T[k] |= f[k];
+            }
+          uint32_t any = 0;
 #pragma unroll
-            for (int w = 0; w < NW; w++) S[w] = T[w] & rc[w] & am[w];
-            pc = hg_prev_ctx(c);
-          }
+          for (int u = 0; u < NW; u++) any |= S[u] = T[u] & rc[u] & am[u];
+          pc = hg_prev_ctx(c);
+          if (any == 0 && at >= fs) alive = false;  // nothing alive and no start left
         }
       }
     }
@@ -321,14 +345,21 @@ __device__ __forceinline__ void confirm_ctx(const uint8_t *text, uint64_t nbytes
       break;
     }
   }
-  if (first_to == HG_NONE32) {  // match ending exactly at the end of the scanned bytes
+  if (first_to == HG_NONE32 && alive) {  // the walk reached the end of the scanned bytes: a match may end exactly there
     const lds_u32 *ac = acct + (pc * 5 + HG_NC_END) * NW;
     uint32_t hit = 0;
 #pragma unroll
-    for (int w = 0; w < NW; w++) hit |= S[w] & ac[w];
-    if (hit) first_to = static_cast<uint32_t>(z - a);
+    for (int u = 0; u < NW; u++) hit |= S[u] & ac[u];
+    if (hit) {
+      first_to = static_cast<uint32_t>(z - a);
+      emit(w.line_no, first_to, a, static_cast<uint32_t>(z - a));
+    }
+    return;
   }
-  if (first_to != HG_NONE32) emit(line_no, first_to, a, static_cast<uint32_t>(z - a));
+  if (first_to != HG_NONE32) {
+    const uint64_t e = a + first_to;
+    emit(w.line_no, first_to, a, static_cast<uint32_t>((e > a ? window_scanned_end(text, e, limit) : scanned_end(text, e, limit)) - a));
+  }
 }
 
 }  // namespace hgdev

@@ -246,6 +246,97 @@ HG_HD void hg_nfa_scan(const uint32_t *pool, const HgPattern &p, const uint8_t *
   if (any) emit(static_cast<uint32_t>(len));
 }
 
+// The same automaton restricted to matches that START in data[from, upto): the step S' = (init | follow(S)) & reach[c] & mask
+// is linear in (init, S), so the start states are injected only at those bytes, the left context at `from` comes from
+// data[from - 1], and the run ends as soon as no state is alive past `upto`.  emit(to) per distinct end of such a match
+// (ascending); returns after the first when `single`.  Used where one scan unit is split by match start (hg_block_small_kernel)
+// and by the windowed confirm (hg_confirm_window below, hg_confirm_dev.h on the device).
+template <typename Emit>
+HG_HD void hg_nfa_scan_slice(const uint32_t *pool, const HgPattern &p, const uint8_t *data, uint32_t len, uint32_t from, uint32_t upto, Emit &&emit) {
+  const uint32_t nw = p.nw;
+  const uint32_t *reach = pool + p.reach_off, *follow = pool + p.follow_off, *init = pool + p.init_off;
+  const uint32_t *amask = pool + p.amask_off, *acc = pool + p.acc_off;
+  const bool single = p.single != 0;
+  uint32_t pc = from ? hg_prev_ctx(data[from - 1]) : HG_PC_START;
+  if (nw == 1) {
+    uint32_t S = 0;
+    const uint32_t init0 = init[0];
+    for (uint32_t i = from; i < len; i++) {
+      if (i >= upto && S == 0) return;  // no start left and nothing alive
+      const uint32_t c = data[i];
+      const uint32_t cc = c == '\n' ? (i + 1 == len ? HG_NC_NLFINAL : HG_NC_NL) : (hg_is_word(c) ? HG_NC_WORD : HG_NC_OTHER);
+      if (S & acc[pc * 5 + cc]) {
+        emit(i);
+        if (single) return;
+      }
+      uint32_t T = i < upto ? init0 : 0u;
+      for (uint32_t x = S; x; x &= x - 1) T |= follow[hg_ctz(x)];
+      S = T & reach[c] & amask[pc * 4 + cc];
+      pc = hg_prev_ctx(c);
+    }
+    if (S & acc[pc * 5 + HG_NC_END]) emit(len);
+    return;
+  }
+  uint32_t S[HG_MAX_W], T[HG_MAX_W];
+  for (uint32_t w = 0; w < nw; w++) S[w] = 0;
+  uint32_t alive = 0;
+  for (uint32_t i = from; i < len; i++) {
+    if (i >= upto && alive == 0) return;
+    const uint32_t c = data[i];
+    const uint32_t cc = c == '\n' ? (i + 1 == len ? HG_NC_NLFINAL : HG_NC_NL) : (hg_is_word(c) ? HG_NC_WORD : HG_NC_OTHER);
+    const uint32_t *a = acc + (pc * 5 + cc) * nw;
+    uint32_t any = 0;
+    for (uint32_t w = 0; w < nw; w++) any |= S[w] & a[w];
+    if (any) {
+      emit(i);
+      if (single) return;
+    }
+    for (uint32_t w = 0; w < nw; w++) T[w] = i < upto ? init[w] : 0u;
+    for (uint32_t w = 0; w < nw; w++)
+      for (uint32_t x = S[w]; x; x &= x - 1) {
+        const uint32_t *f = follow + (w * 32 + hg_ctz(x)) * nw;
+        for (uint32_t k = 0; k < nw; k++) T[k] |= f[k];
+      }
+    const uint32_t *r = reach + c * nw, *m = amask + (pc * 4 + cc) * nw;
+    alive = 0;
+    for (uint32_t w = 0; w < nw; w++) alive |= S[w] = T[w] & r[w] & m[w];
+    pc = hg_prev_ctx(c);
+  }
+  const uint32_t *a = acc + (pc * 5 + HG_NC_END) * nw;
+  uint32_t any = 0;
+  for (uint32_t w = 0; w < nw; w++) any |= S[w] & a[w];
+  if (any) emit(len);
+}
+
+
+// Confirm by WINDOW: what the device's confirm routines for SINGLEMATCH automata compute (hg_confirm_dev.h has the argument).
+// Every match contains an occurrence of the pattern's required literal that begins at most `lit_lead` bytes after the
+// match's start; the candidate whose verified occurrence begins at `fs` answers for the matches that start in
+// [fs - lit_lead, fs].  emit(line_no, to, a, len) for the smallest end of such a match.
+template <typename Emit>
+HG_HD void hg_confirm_window(const HgDbView &db, const uint8_t *text, uint64_t nbytes, const HgTileSum *sums, const HgTileBase *bases, uint64_t bs1, uint64_t pos,
+                             uint64_t fs, uint32_t pattern, uint32_t rank, Emit &&emit) {
+  uint64_t t = pos >> HG_TILE_SHIFT, tile_start = t << HG_TILE_SHIFT;
+  uint64_t s;
+  if (rank == 0) {
+    s = bases[t].cs;
+  } else {
+    s = pos;  // the previous '\n' lies inside this tile
+    while (s > tile_start && text[s - 1] != '\n') s--;
+  }
+  uint64_t k = (pos - s) / bs1;
+  uint64_t ps = s + k * bs1;
+  uint64_t line_no = hg_line_index(text, sums[t], bases[t], tile_start, rank, s, bs1, bs1 < HG_TILE_BYTES) + k;
+  uint64_t limit = ps + bs1 < nbytes ? ps + bs1 : nbytes;
+  uint64_t a, z;
+  hg_trim_piece(text, ps, limit, a, z);
+  if (z <= a || pos < a || pos >= z || fs < a) return;  // the occurrence does not lie in the scanned bytes
+  const HgPattern &p = db.patterns[pattern];
+  const uint64_t q = (p.lit_lead != 0xFFFFFFFFu && fs - a > p.lit_lead) ? fs - p.lit_lead : a;
+  hg_nfa_scan_slice(db.pool, p, text + a, static_cast<uint32_t>(z - a), static_cast<uint32_t>(q - a), static_cast<uint32_t>(fs - a + 1),
+                    [&](uint32_t to) { emit(line_no, to, a, static_cast<uint32_t>(z - a)); });
+}
+
 // Confirm one candidate: locate the piece containing byte `pos`, trim it, run the pattern.
 // emit(line_no, to, a, len) per report.
 template <typename Emit>

@@ -77,8 +77,10 @@ struct HgPattern {
   uint32_t init_word;   // init[0] when `simple`
   uint32_t literal_only;  // the whole expression is one literal (its factor): a verified occurrence IS the match
   uint32_t max_len;       // longest possible match in bytes, 0 = unbounded (literal_only: the literal's length)
+  uint32_t lit_lead;      // tier 0: every match contains one of the pattern's required literals starting at most this many bytes
+                          // after the match's start (0xFFFFFFFF: no bound) — the confirm routines' window (hg_confirm_dev.h)
 };
-static_assert(sizeof(HgPattern) == 64, "HgPattern layout");
+static_assert(sizeof(HgPattern) == 68, "HgPattern layout");
 
 // A required literal of one pattern ("factor"): any match of the pattern contains an occurrence.
 struct HgFactor {

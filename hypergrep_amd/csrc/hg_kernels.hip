@@ -1128,9 +1128,20 @@ __device__ __forceinline__ void confirm_tables_body(const HgConfirmArgs &a, uint
   if (cnt > a.defer_shard_cap) cnt = a.defer_shard_cap;
   const uint32_t incl = wave_inclusive_scan(cnt, lane), start = incl - cnt;
   const uint32_t total = __shfl(incl, 63, 64);
+  // no more blocks than give every wave a full batch of 64 (the others leave at once: an idle block is a resident block)
+  const uint32_t busy = total ? (total + HG_CONFIRM_THREADS - 1) / HG_CONFIRM_THREADS : 0u;
+  if (busy < vgrid) vgrid = busy;
+  if (vblock >= vgrid) return;  // (block-uniform; nothing staged: nothing to flush)
   const uint32_t lo = static_cast<uint32_t>(static_cast<uint64_t>(total) * vblock / vgrid), hi = static_cast<uint32_t>(static_cast<uint64_t>(total) * (vblock + 1) / vgrid);
   const HgDeferred *lists = a.deferred + static_cast<uint64_t>(a.list_of_mode[MODE]) * HG_DEFER_SHARDS * a.defer_shard_cap;
+#ifdef HG_PROFILE_CONFIRM
+  uint64_t pf_load = 0, pf_stage = 0, pf_run = 0;
+  uint32_t pf_pats = 0;
+#endif
   for (uint32_t g0 = lo + wave * 64u; g0 < hi; g0 += HG_CONFIRM_THREADS) {  // wave-uniform
+#ifdef HG_PROFILE_CONFIRM
+    uint64_t pf_t = wall_clock64();
+#endif
     const uint32_t g = g0 + lane;
     // list holding item g: the last list whose exclusive prefix is <= g
     uint32_t list = 0;
@@ -1145,6 +1156,9 @@ __device__ __forceinline__ void confirm_tables_body(const HgConfirmArgs &a, uint
     HgDeferred d{0, 0, 0};
     if (valid) d = lists[static_cast<uint64_t>(list) * a.defer_shard_cap + (g - l_start)];
     const uint32_t pattern = d.pattern & (HG_MAX_PATTERNS - 1u);
+#ifdef HG_PROFILE_CONFIRM
+    { const uint64_t n = wall_clock64(); pf_load += n - pf_t; pf_t = n; }
+#endif
     for (uint64_t todo = __builtin_amdgcn_ballot_w64(valid); todo;) {  // one pattern at a time
       const uint32_t pat = __builtin_amdgcn_readlane(pattern, __builtin_ctzll(todo));
       const bool mine = valid && pattern == pat;
@@ -1154,22 +1168,33 @@ __device__ __forceinline__ void confirm_tables_body(const HgConfirmArgs &a, uint
       stage_tables<MODE == 2>(tab, a.db.pool, p, nw, lane);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+#ifdef HG_PROFILE_CONFIRM
+      { const uint64_t n = wall_clock64(); pf_stage += n - pf_t; pf_t = n; pf_pats++; }
+#endif
       if (mine) {
         const uint32_t id = p.id;
         auto emit = [&](uint64_t line_no, uint32_t to, uint64_t start_, uint32_t len) { sink.push(a, line_no, id, to, start_, len, pat, true); };
+        const uint64_t fs = d.pos - (d.pattern >> 24);  // where the verified literal occurrence begins
+        const uint32_t lead = p.lit_lead;
         if (MODE == 1) {
-          hgdev::confirm_simple(a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, d.rank, p.init_word, p.acc_all, tab + CT_REACH, tab + CT_FOLLOW, emit);
+          hgdev::confirm_simple(a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, d.rank, fs, lead, p.init_word, p.acc_all, tab + CT_REACH, tab + CT_FOLLOW, emit);
         } else if (nw == 1) {
-          hgdev::confirm_ctx<1>(a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, d.rank, tab + CT_REACH, tab + CT_FOLLOW, tab + CT_INIT, tab + CT_AMASK, tab + CT_ACC,
-                                    emit);
+          hgdev::confirm_ctx<1>(a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, d.rank, fs, lead, tab + CT_REACH, tab + CT_FOLLOW, tab + CT_INIT, tab + CT_AMASK,
+                                    tab + CT_ACC, emit);
         } else {
-          hgdev::confirm_ctx<2>(a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, d.rank, tab + CT_REACH, tab + CT_FOLLOW, tab + CT_INIT, tab + CT_AMASK, tab + CT_ACC,
-                                    emit);
+          hgdev::confirm_ctx<2>(a.text, a.nbytes, a.sums, a.bases, a.bs1, d.pos, d.rank, fs, lead, tab + CT_REACH, tab + CT_FOLLOW, tab + CT_INIT, tab + CT_AMASK,
+                                    tab + CT_ACC, emit);
         }
       }
       __builtin_amdgcn_wave_barrier();  // the next pattern's tables overwrite this one's
+#ifdef HG_PROFILE_CONFIRM
+      { const uint64_t n = wall_clock64(); pf_run += n - pf_t; pf_t = n; }
+#endif
     }
   }
+#ifdef HG_PROFILE_CONFIRM
+  if (lane == 0) a.tmp_hits[(6u << 20) + 32768u + blockIdx.x * (HG_CONFIRM_THREADS / 64) + wave] = HgHit{pf_load | (pf_stage << 32), static_cast<uint32_t>(pf_run), pf_pats | (MODE << 28)};
+#endif
   flush_hits(a, &s_n, &s_base);
 }
 
@@ -1177,20 +1202,31 @@ __device__ __forceinline__ void confirm_tables_body(const HgConfirmArgs &a, uint
 // passes cost three latency tails, side by side one): blocks [k * blocks_per_mode, (k+1) * blocks_per_mode) work on the
 // k-th mode present in the database.
 __global__ __launch_bounds__(HG_CONFIRM_THREADS) void hg_confirm_fast_kernel(HgConfirmArgs a, uint32_t blocks_per_mode) {
-  // blocks of the modes alternate in launch order (block b works for the (b mod #modes)-th mode present, slowest routine
-  // first): every mode progresses from the first round of blocks on, instead of the automaton modes — few items, long
-  // chains — starting when the literal-only blocks are through
+  // Launch order = slowest routine first, mode by mode (per-wave timing, tools/confirm_waves.py: a batch of the routine with
+  // boundary conditions takes 200-280 us, one of the context-free routine 70, a literal-only one 40; 9216 blocks are 3.6
+  // rounds of resident blocks, and with the modes alternating the last long batch STARTED 214 us into a 405 us kernel):
+  // the long batches all start in the first round and the short ones fill in behind them.
   uint32_t nmodes = 0;
   for (uint32_t m = 0; m < 3; m++) nmodes += a.mode_present[m] ? 1u : 0u;
   if (nmodes == 0) return;
-  const uint32_t k = nmodes - 1u - blockIdx.x % nmodes, vblock = blockIdx.x / nmodes;  // block-uniform
+  const uint32_t k = nmodes - 1u - blockIdx.x / blocks_per_mode, vblock = blockIdx.x % blocks_per_mode;  // block-uniform
   uint32_t mode = 0, seen = 0;
   for (uint32_t m = 0; m < 3; m++)
     if (a.mode_present[m] && seen++ == k) mode = m;
   __shared__ __attribute__((aligned(16))) uint32_t s_tab[(HG_CONFIRM_THREADS / 64) * CT_WORDS];  // a table area per wave (modes 1, 2)
+#ifdef HG_PROFILE_CONFIRM
+  const uint64_t t0 = wall_clock64();
+#endif
   if (mode == 0) confirm_body<0>(a, vblock, blocks_per_mode);
   else if (mode == 1) confirm_tables_body<1>(a, vblock, blocks_per_mode, s_tab);
   else confirm_tables_body<2>(a, vblock, blocks_per_mode, s_tab);
+#ifdef HG_PROFILE_CONFIRM
+  if ((threadIdx.x & 63u) == 0) {  // per wave: start, end (100 MHz ticks), mode, block: into the unused end of the staging array
+    const uint64_t t1 = wall_clock64();
+    const uint32_t w = blockIdx.x * (HG_CONFIRM_THREADS / 64) + (threadIdx.x >> 6);
+    a.tmp_hits[(6u << 20) + w] = HgHit{t0, static_cast<uint32_t>(t1 - t0), mode | (vblock << 4)};
+  }
+#endif
 }
 __global__ __launch_bounds__(256) void hg_confirm_generic_kernel(HgConfirmArgs a) { confirm_body<3>(a, blockIdx.x, gridDim.x); }
 
@@ -1761,63 +1797,6 @@ __global__ __launch_bounds__(256) void hg_block_scan_kernel(HgConfirmArgs a, con
 // at the slice's bytes and runs on past its end until no state is alive (a literal's partial match dies within a few bytes;
 // an expression with .* runs to the end of the block, as before).  The same end found from two slices is emitted once
 // (a bitmap of ends per expression in LDS).
-template <typename Emit>
-__device__ __forceinline__ void hg_nfa_scan_slice(const uint32_t *pool, const HgPattern &p, const uint8_t *data, uint32_t len, uint32_t from, uint32_t upto, Emit &&emit) {
-  const uint32_t nw = p.nw;
-  const uint32_t *reach = pool + p.reach_off, *follow = pool + p.follow_off, *init = pool + p.init_off;
-  const uint32_t *amask = pool + p.amask_off, *acc = pool + p.acc_off;
-  const bool single = p.single != 0;
-  uint32_t pc = from ? hg_prev_ctx(data[from - 1]) : HG_PC_START;
-  if (nw == 1) {
-    uint32_t S = 0;
-    const uint32_t init0 = init[0];
-    for (uint32_t i = from; i < len; i++) {
-      if (i >= upto && S == 0) return;  // no start left and nothing alive
-      const uint32_t c = data[i];
-      const uint32_t cc = c == '\n' ? (i + 1 == len ? HG_NC_NLFINAL : HG_NC_NL) : (hg_is_word(c) ? HG_NC_WORD : HG_NC_OTHER);
-      if (S & acc[pc * 5 + cc]) {
-        emit(i);
-        if (single) return;
-      }
-      uint32_t T = i < upto ? init0 : 0u;
-      for (uint32_t x = S; x; x &= x - 1) T |= follow[hg_ctz(x)];
-      S = T & reach[c] & amask[pc * 4 + cc];
-      pc = hg_prev_ctx(c);
-    }
-    if (S & acc[pc * 5 + HG_NC_END]) emit(len);
-    return;
-  }
-  uint32_t S[HG_MAX_W], T[HG_MAX_W];
-  for (uint32_t w = 0; w < nw; w++) S[w] = 0;
-  uint32_t alive = 0;
-  for (uint32_t i = from; i < len; i++) {
-    if (i >= upto && alive == 0) return;
-    const uint32_t c = data[i];
-    const uint32_t cc = c == '\n' ? (i + 1 == len ? HG_NC_NLFINAL : HG_NC_NL) : (hg_is_word(c) ? HG_NC_WORD : HG_NC_OTHER);
-    const uint32_t *a = acc + (pc * 5 + cc) * nw;
-    uint32_t any = 0;
-    for (uint32_t w = 0; w < nw; w++) any |= S[w] & a[w];
-    if (any) {
-      emit(i);
-      if (single) return;
-    }
-    for (uint32_t w = 0; w < nw; w++) T[w] = i < upto ? init[w] : 0u;
-    for (uint32_t w = 0; w < nw; w++)
-      for (uint32_t x = S[w]; x; x &= x - 1) {
-        const uint32_t *f = follow + (w * 32 + hg_ctz(x)) * nw;
-        for (uint32_t k = 0; k < nw; k++) T[k] |= f[k];
-      }
-    const uint32_t *r = reach + c * nw, *m = amask + (pc * 4 + cc) * nw;
-    alive = 0;
-    for (uint32_t w = 0; w < nw; w++) alive |= S[w] = T[w] & r[w] & m[w];
-    pc = hg_prev_ctx(c);
-  }
-  const uint32_t *a = acc + (pc * 5 + HG_NC_END) * nw;
-  uint32_t any = 0;
-  for (uint32_t w = 0; w < nw; w++) any |= S[w] & a[w];
-  if (any) emit(len);
-}
-
 __global__ __launch_bounds__(256) void hg_block_small_kernel(HgDbView db, const uint8_t *h_text, uint32_t length, HgHit *h_out, uint32_t seg_cap, uint32_t *h_counts,
                                                              uint32_t *d_done, uint32_t *h_flag, uint32_t seq, uint32_t ppw) {
   __shared__ __attribute__((aligned(16))) uint8_t s_text[HG_BLOCK_SMALL_MAX + 16];

@@ -245,13 +245,18 @@ long hgsim_scan(void *h, const uint8_t *data, uint64_t nbytes, int buffer_size, 
   std::vector<HgHitAux> aux;
   uint64_t verified = 0;
   for (auto &c : cands) {
-    hg_verify_window(v, data, nbytes, c.pos, c.word, [&](uint32_t pattern, uint64_t, uint32_t) {
+    hg_verify_window(v, data, nbytes, c.pos, c.word, [&](uint32_t pattern, uint64_t fs, uint32_t) {
       verified++;
-      hg_confirm(v, data, nbytes, sums.data(), bases.data(), bs1, c.pos, pattern, c.rank,
-                 [&](uint64_t line_no, uint32_t to, uint64_t a, uint32_t len) {
-                   hits.push_back(HgHit{line_no, db->patterns[pattern].id, to});
-                   aux.push_back(HgHitAux{a, len, pattern});
-                 });
+      auto emit = [&](uint64_t line_no, uint32_t to, uint64_t a, uint32_t len) {
+        hits.push_back(HgHit{line_no, db->patterns[pattern].id, to});
+        aux.push_back(HgHitAux{a, len, pattern});
+      };
+      // SINGLEMATCH automata of <= 2 state words are confirmed by window on the device (confirm modes 1 and 2): the same here
+      const uint32_t mode = hg_confirm_mode(db->patterns[pattern]);
+      if ((mode == 1 || mode == 2) && !getenv("HGSIM_NO_WINDOW"))
+        hg_confirm_window(v, data, nbytes, sums.data(), bases.data(), bs1, c.pos, fs, pattern, c.rank, emit);
+      else
+        hg_confirm(v, data, nbytes, sums.data(), bases.data(), bs1, c.pos, pattern, c.rank, emit);
     });
   }
   // ---- always-on tier: every line start

@@ -391,6 +391,36 @@ def test_random_literal_anchored_patterns_match_oracle(seed):
     assert len(want) > 50 and db.info()["nslow"] == 0
 
 
+def test_windowed_confirm_lead_of_the_required_literal():
+    """SINGLEMATCH automata are confirmed on a window: matches that start at most `lit_lead` bytes before the verified
+    occurrence of the required literal (hg_core.h hg_confirm_window, the host mirror of hg_confirm_dev.h).  Expressions
+    whose literal follows optional, alternative, bounded and unbounded prefixes, repeated groups holding the literal,
+    assertions either side, several occurrences per line, overlapping matches: the smallest end per line must not change."""
+    rng = random.Random(515)
+    pats = ["[a-z]{0,3}needle_alpha_1", "(?:ab|cde)?needle_beta_22 tail", "x*needle_gamma_3+", "(?:aa|b)+needle_delta_4", "\\b[0-9]{2,5}-needle_eps_5\\b",
+            "(?:pre_needle_zeta_6|needle_zeta_6x)[0-9]", "q?(?:needle_eta_77){1,3}z", "[A-Z][a-z]+ needle_theta_8$", "^.{0,6}needle_iota_9", "(?i)u{2,}Needle_Kappa_10",
+            "(?:foo(?:needle_lambda_11|bar_needle_mu_12)){1,2}!", "a.c.e needle_nu_13"]
+    flags = [14] * len(pats)
+    flags[8] = 10
+    assert oracle_py.check_patterns(pats, flags=flags) == 0
+    pieces = ["needle_alpha_1", "abcneedle_alpha_1", "zzzzzneedle_alpha_1 needle_alpha_1", "abneedle_beta_22 tail", "cdeneedle_beta_22 tail", "needle_beta_22 tai",
+              "xxxxxxneedle_gamma_3333", "needle_gamma_", "aabaaneedle_delta_4", "abneedle_delta_4", "12-needle_eps_5", "123456-needle_eps_5", "x12-needle_eps_5", "99-needle_eps_5x",
+              "pre_needle_zeta_67", "needle_zeta_6x8", "needle_zeta_68", "qneedle_eta_77needle_eta_77z", "needle_eta_77needle_eta_77needle_eta_77needle_eta_77z",
+              "Hello needle_theta_8", "Hello needle_theta_8 more", "abcneedle_iota_9", "abcdefgneedle_iota_9", "uuuuNEEDLE_kappa_10", "uneedle_kappa_10",
+              "fooneedle_lambda_11foobar_needle_mu_12!", "foobar_needle_mu_12!", "fooneedle_lambda_11", "abcde needle_nu_13", "a c e needle_nu_13", "ab de needle_nu_13"]
+    lines = []
+    for _ in range(2500):
+        n = rng.randint(1, 4)
+        lines.append(" ".join(rng.choice(pieces) if rng.random() < 0.6 else "".join(rng.choice("abcxuq 019-AZ") for _ in range(rng.randint(0, 12))) for _ in range(n)))
+    data = ("\n".join(lines) + "\n").encode()
+    for ids in (list(range(len(pats))), [0] * len(pats)):
+        want, nlines = oracle_hits(data, pats, flags, ids)
+        got, stats, db = sim_hits(data, pats, flags, ids)
+        assert all(db.tier(i) == 0 for i in range(len(pats)))
+        assert got == want
+        assert len(want) > 1500
+
+
 # ---- match END offsets of the product's automata against the Python-`re` brute force (regex_gen.ends_by_brute_force):
 # independent of the oracle, which the same brute force pins in tests/test_oracle.py
 @pytest.mark.parametrize("seed", range(20))
