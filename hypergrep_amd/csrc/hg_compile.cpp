@@ -1501,13 +1501,16 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
     db->nslow_fast = static_cast<uint32_t>(std::count_if(db->slow.begin(), db->slow.end(), two_words));
     build_slow_groups(*db);
     // factors (needs the final fold mask); windows and filter tables are built from them
+    uint32_t rank_in_mode[HG_CONFIRM_MODES] = {0, 0, 0, 0};
     for (unsigned i = 0; i < n; i++) {
       if (db->patterns[i].tier != 0) continue;
+      const uint32_t mode = hg_confirm_mode(db->patterns[i]), rank = rank_in_mode[mode]++;
       for (auto &l : covers[i].lits) {
         HgFactor fct{};
         fct.pattern = i;
         fct.len = static_cast<uint32_t>(l.bytes.size());
-        fct.mode = hg_confirm_mode(db->patterns[i]);
+        fct.mode = mode;
+        fct.mode_rank = rank;
         std::memcpy(fct.lit, l.bytes.data(), fct.len);
         std::memcpy(fct.cmask, l.cmask.data(), fct.len);
         db->factors.push_back(fct);

@@ -87,7 +87,8 @@ struct HgFactor {
   uint32_t pattern;              // index into patterns[]
   uint32_t len;                  // <= HG_FACTOR_MAX
   uint32_t mode;                 // confirm routine of the pattern (hg_confirm_mode), copied here so the verify pass needs no pattern load
-  uint32_t pad;
+  uint32_t mode_rank;            // the pattern's rank among the patterns of its confirm mode: names its verified-occurrence lists (no two
+                                 // patterns of a mode share a list while the mode has at most HG_DEFER_SHARDS of them)
   uint8_t lit[HG_FACTOR_MAX];    // literal bytes
   uint8_t cmask[HG_FACTOR_MAX];  // 0xFF exact, 0xDF case-insensitive letter
 };

@@ -962,7 +962,7 @@ __global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
       const uint32_t o_rank = __shfl(c.rank, owner, 64);
       const uint64_t pos = (static_cast<uint64_t>(static_cast<uint32_t>(__shfl(pos_hi, owner, 64))) << 32) | static_cast<uint32_t>(__shfl(pos_lo, owner, 64));
       bool ok = false;
-      uint32_t mode = 0, tag = 0;
+      uint32_t mode = 0, tag = 0, mode_rank = 0;
       if (t < total) {
         const HgWindow win = a.db.windows2[o_j0 + (t - o_start)];
         if (win.value == o_folded) {
@@ -989,6 +989,7 @@ __global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
             if (diff == 0) {
               ok = true;
               mode = hdr.z;
+              mode_rank = hdr.w;
               tag = hdr.x | (off << 24);
             }
           }
@@ -1005,7 +1006,9 @@ __global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
           at0 = __builtin_amdgcn_readfirstlane(at0);
           if (ok && mode == m) {
             const uint32_t at = at0 + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mm >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mm), 0u));
-            const uint32_t list = ((tag & (HG_MAX_PATTERNS - 1u)) * a.list_spread[m] + blockIdx.x % a.list_spread[m]) % HG_DEFER_SHARDS;
+            // (by the pattern's rank in its mode, not its index: indices that share a factor with HG_DEFER_SHARDS piled several
+            // patterns into the same lists, and a confirm wave works through the patterns of its batch one after the other)
+            const uint32_t list = (mode_rank * a.list_spread[m] + blockIdx.x % a.list_spread[m]) % HG_DEFER_SHARDS;
             if (at < VERIFY_STAGE_CAP) {
               s_stage.item[at] = HgDeferred{pos, tag, o_rank};
               s_stage.bin[at] = static_cast<uint8_t>((m - 1u) * HG_DEFER_SHARDS + list);
