@@ -345,7 +345,18 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
     const uint32_t wgs_shared = grid_for(per_cu);  // next to the side passes of the previous chunk
     // the first chunk streams alone: every workgroup slot (unless the grid was fixed by hand)
     const uint32_t wgs_alone = std::getenv("HG_STREAM_WGS_PER_CU") ? wgs_shared : grid_for(static_cast<uint32_t>(stream_wgs_per_cu_));
-    wgs = std::max(wgs_shared, wgs_alone);  // sizes the regrowth of the candidate segments
+    // Joiners: the side passes of chunk c - 1 take about half as long as the stream pass of chunk c; behind them, on the side
+    // stream, a second launch of the stream kernel (one more workgroup per CU, its own candidate segments) joins chunk c and
+    // draws tiles from the same cursor until the chunk is used up.
+    // (Only where a CU has room for it: the kernel's LDS allows three workgroups per CU and the shared launches use two.
+    // When the side passes are the slower half — config 5 — the joiner finds the cursor used up and leaves at once.
+    // Measured: 6.99 -> 6.84 ms per 32 GiB on config 3; HG_JOINER=0 turns it off.)
+    // Not for texts so dense in candidates that the chunks had to shrink: their side passes are the slower half anyway, and
+    // the joiner's segments would take workspace from the others.
+    uint32_t joiner_wgs = (piped && stream_wgs_per_cu_ >= 3 && per_cu < static_cast<uint32_t>(stream_wgs_per_cu_) && chunk_limit_tiles_ == 0) ? static_cast<uint32_t>(num_cus_) : 0u;
+    if (const char *env = std::getenv("HG_JOINER")) joiner_wgs = piped ? static_cast<uint32_t>(std::max(0l, std::min(2l, std::strtol(env, nullptr, 10)))) * static_cast<uint32_t>(num_cus_) : 0u;
+    if (wgs_shared + joiner_wgs > max_segs_) joiner_wgs = 0;
+    wgs = std::max(wgs_shared + joiner_wgs, wgs_alone);  // sizes the regrowth of the candidate segments
     hipStream_t side = piped ? side_stream_ : stream;
     if (piped && !ev_side_done_[0]) {
       for (int i = 0; i < kMaxChunks; i++) {
@@ -402,7 +413,8 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       sa.sums = d_sums_;
       sa.cands = cands;
       sa.seg_count = seg_count;
-      const uint32_t segs_c = wgs_c;  // candidate segments of the chunk: one per stream workgroup
+      const uint32_t joiners_c = c >= 1 ? joiner_wgs : 0u;
+      const uint32_t segs_c = wgs_c + joiners_c;  // candidate segments of the chunk: one per stream workgroup
       sa.cand_seg_cap = cand_cap_ / segs_c;
       sa.alone = (c == 0 && wgs_c == wgs_alone && !std::getenv("HG_STREAM_WGS_PER_CU")) ? 1u : 0u;
       sa.counters = d_counters_;
@@ -413,6 +425,14 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       }
       HG_TRY(hipGetLastError(), "hg_stream_kernel launch");
       HG_TRY(hipEventRecord(piped ? ev_k1_end_[c] : ev_[2], stream), "event");
+      if (joiners_c) {  // (the side stream: behind the side passes of chunk c - 1, in front of those of chunk c)
+        HgStreamArgs ja = sa;
+        ja.cands = cands + static_cast<uint64_t>(wgs_c) * sa.cand_seg_cap;
+        ja.seg_count = seg_count + wgs_c;
+        ja.alone = 0;
+        if (!hg_launch_stream(ja, joiners_c, side)) return HG_ERR_ARG;
+        HG_TRY(hipGetLastError(), "hg_stream_kernel launch (joiner)");
+      }
       if (piped) HG_TRY(hipStreamWaitEvent(side, ev_k1_end_[c], 0), "stream wait");
 
       HgConfirmArgs ca{};
