@@ -41,6 +41,7 @@ constexpr uint32_t HG_STREAM_GRAB = 2 * HG_STREAM_WG_WAVES_DEFAULT;  // tiles pe
 // Bucketed finalize (hg_fin_*): buckets of the final ordering and the largest bucket one wave sorts in LDS.
 constexpr uint32_t HG_FIN_MAX_BUCKETS = 1u << 20;
 constexpr uint32_t HG_FIN_BUCKET_CAP = 4096;
+constexpr uint32_t HG_FIN_MEDIUM_CAP = 512;  // size class of hg_fin_sort_big_kernel that needs little LDS
 
 // Threads of a confirm block: its LDS (the per-lane follow tables of the one-word automata, 128 B per lane) decides how many
 // fit on a CU next to the stream pass.

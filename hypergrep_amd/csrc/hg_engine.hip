@@ -34,8 +34,9 @@ __global__ void hg_reset_kernel(uint32_t *state, uint32_t state_words, HgTileBas
                                 uint32_t ndefer);
 __global__ void hg_fin_sort_small_kernel(const HgHit *hits, uint32_t *idx, const uint32_t *fill, uint32_t b_lo, uint32_t b_hi, uint32_t cap, uint32_t id_bits,
                                          uint32_t to_bits, uint32_t *kept_count, uint32_t *big_list, uint32_t *big_count);
+template <uint32_t LCAP, bool IN_LDS>
 __global__ void hg_fin_sort_big_kernel(const HgHit *hits, uint32_t *idx, const uint32_t *fill, const uint32_t *big_list, const uint32_t *big_count, uint32_t cap,
-                                       uint32_t id_bits, uint32_t to_bits, uint32_t *kept_count, uint32_t *overflow);
+                                       uint32_t id_bits, uint32_t to_bits, uint32_t *kept_count, uint32_t *overflow, uint64_t *scratch_key, uint32_t *scratch_idx);
 __global__ void hg_fin_scan_kernel(uint32_t *kept_count, uint32_t b_lo, uint32_t b_hi, uint32_t *total, const uint32_t *fill, uint32_t cap);
 __global__ void hg_fin_gather_kernel(const HgHit *hits, const HgHitAux *aux, const uint32_t *idx, const uint32_t *kept_base, const uint32_t *total, uint32_t b_lo,
                                      uint32_t b_hi, uint32_t cap, HgHit *oh, HgHitAux *oa);
@@ -145,7 +146,7 @@ int HgScanner::create(std::shared_ptr<const HgDb> db, int device, HgScanner **ou
 
   HG_TRY(hgmem::dev_alloc(&s->d_fin_fill_, HG_FIN_MAX_BUCKETS * 4, "d_fin_fill_"), "alloc finalize buckets");
   HG_TRY(hgmem::dev_alloc(&s->d_fin_kept_, HG_FIN_MAX_BUCKETS * 4, "d_fin_kept_"), "alloc finalize buckets");
-  HG_TRY(hgmem::dev_alloc(&s->d_fin_big_, HG_FIN_MAX_BUCKETS * 4, "d_fin_big_"), "alloc finalize buckets");
+  HG_TRY(hgmem::dev_alloc(&s->d_fin_big_, 2 * HG_FIN_MAX_BUCKETS * 4, "d_fin_big_"), "alloc finalize buckets");  // (two work lists)
   // (the per-chunk events of the two-stream pipeline are created by the first scan that is large enough to use it: a
   // process that keeps dozens of scanners for small files would otherwise hold thousands of events for nothing)
 #undef HG_TRY
@@ -265,7 +266,9 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   if (own_len) {
     const uint64_t expect = std::max<uint64_t>(fin_expect_hits_, own_len >> 13);
     uint64_t want_nb = 1;
-    while (want_nb * 48 < expect && want_nb < HG_FIN_MAX_BUCKETS) want_nb <<= 1;
+    uint64_t per_bucket = 48;
+    if (const char *env = std::getenv("HG_FIN_TARGET")) per_bucket = std::max<uint64_t>(4, std::strtoull(env, nullptr, 10));
+    while (want_nb * per_bucket < expect && want_nb < HG_FIN_MAX_BUCKETS) want_nb <<= 1;
     while (((own_len - 1) >> fin_shift) >= want_nb) fin_shift++;
     fin_nb = static_cast<uint32_t>((own_len - 1) >> fin_shift) + 1;
   }
@@ -373,12 +376,17 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
     auto launch_fin = [&](hipStream_t s, uint32_t lo, uint32_t hi) -> int {
       if (hi <= lo) return HG_OK;
       const uint32_t nbk = hi - lo, cu = static_cast<uint32_t>(num_cus_);
-      HG_TRY(hipMemsetAsync(d_fin_total_ + 2, 0, 4, s), "memset work list");  // (large buckets of this range)
+      HG_TRY(hipMemsetAsync(d_fin_total_ + 2, 0, 8, s), "memset work list");  // (larger buckets of this range: two size classes)
       hipLaunchKernelGGL(hg_fin_sort_small_kernel, dim3(std::min<uint32_t>((nbk + 3) / 4, cu * 8)), dim3(256), 0, s, d_hits_raw_, d_perm_a_, d_fin_fill_, lo, hi, fin_cap, id_bits, to_bits,
                          d_fin_kept_, d_fin_big_, d_fin_total_ + 2);
-      hipLaunchKernelGGL(hg_fin_sort_big_kernel, dim3(std::min<uint32_t>(nbk, cu * 3)), dim3(256), 0, s, d_hits_raw_, d_perm_a_, d_fin_fill_, d_fin_big_, d_fin_total_ + 2, fin_cap, id_bits,
-                         to_bits, d_fin_kept_, d_selected_ + 1);
-      hipLaunchKernelGGL(hg_fin_scan_kernel, dim3(1), dim3(1024), 0, s, d_fin_kept_, lo, hi, d_fin_total_, d_fin_fill_, fin_cap);
+      hipLaunchKernelGGL((hg_fin_sort_big_kernel<HG_FIN_MEDIUM_CAP, true>), dim3(std::min<uint32_t>(nbk, cu * 4)), dim3(256), 0, s, d_hits_raw_, d_perm_a_, d_fin_fill_, d_fin_big_, d_fin_total_ + 2,
+                         fin_cap, id_bits, to_bits, d_fin_kept_, d_selected_ + 1, static_cast<uint64_t *>(nullptr), static_cast<uint32_t *>(nullptr));
+      // (scratch of the large class: the key / permutation arrays of the library sort, idle while the scanner emits into buckets)
+      const uint32_t big_blocks = std::min<uint32_t>(std::min<uint32_t>(nbk, 64u), hit_cap_ / HG_FIN_BUCKET_CAP);
+      if (big_blocks)
+        hipLaunchKernelGGL((hg_fin_sort_big_kernel<HG_FIN_BUCKET_CAP, false>), dim3(big_blocks), dim3(256), 0, s, d_hits_raw_, d_perm_a_, d_fin_fill_, d_fin_big_ + HG_FIN_MAX_BUCKETS,
+                           d_fin_total_ + 3, fin_cap, id_bits, to_bits, d_fin_kept_, d_selected_ + 1, d_key_a_, d_perm_b_);
+      hipLaunchKernelGGL(hg_fin_scan_kernel, dim3(1), dim3(512), 0, s, d_fin_kept_, lo, hi, d_fin_total_, d_fin_fill_, fin_cap);
       hipLaunchKernelGGL(hg_fin_gather_kernel, dim3(std::min<uint32_t>((nbk + 3) / 4, cu * 8)), dim3(256), 0, s, d_hits_raw_, d_aux_raw_, d_perm_a_, d_fin_kept_, d_fin_total_, lo, hi, fin_cap,
                          d_hits_out_, d_aux_out_);
       HG_TRY(hipGetLastError(), "finalize launch");
@@ -425,6 +433,19 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       }
       HG_TRY(hipGetLastError(), "hg_stream_kernel launch");
       HG_TRY(hipEventRecord(piped ? ev_k1_end_[c] : ev_[2], stream), "event");
+      if (piped && bucketed && joiners_c && c + 1 == nchunks && !std::getenv("HG_NO_EARLY_FINALIZE")) {
+        // The last chunk: the side stream is idle from the end of chunk c - 1's side passes to the end of this stream launch.
+        // The buckets the earlier chunks have completed are finalized there, in front of the joiner (they used to be
+        // finalized beside the last chunk's verify / confirm passes, competing with them for the chip: 430 us for what takes
+        // 150 alone, and last to finish).
+        const uint64_t prev_end = std::min<uint64_t>(t0 << HG_TILE_SHIFT, nbytes);
+        const uint64_t settled = prev_end > bs1 ? prev_end - bs1 : 0;
+        const uint32_t lim = static_cast<uint32_t>(std::min<uint64_t>((settled > range.own_lo ? settled - range.own_lo : 0) >> fin_shift, fin_nb));
+        if (lim > fin_done) {
+          if (int rc = launch_fin(side, fin_done, lim)) return rc;
+          fin_done = lim;
+        }
+      }
       if (joiners_c) {  // (the side stream: behind the side passes of chunk c - 1, in front of those of chunk c)
         HgStreamArgs ja = sa;
         ja.cands = cands + static_cast<uint64_t>(wgs_c) * sa.cand_seg_cap;

@@ -1916,8 +1916,11 @@ __global__ __launch_bounds__(256) void hg_fin_sort_small_kernel(const HgHit *hit
     h_next = make_uint4(0, 0, 0, 0);
     if (bn < b_hi && lane < cap) h_next = hits4[static_cast<uint64_t>(bn) * cap + lane];
     if (n > cap) n = cap;  // (overflowed: the pass is repeated anyway)
-    if (n > 64) {  // hg_fin_sort_big_kernel's: noted in its work list
-      if (lane == 0) big_list[atomicAdd(big_count, 1u)] = b;
+    if (n > 64) {  // hg_fin_sort_big_kernel's: noted in the work list of its size class (up to HG_FIN_MEDIUM_CAP records / more)
+      if (lane == 0) {
+        const uint32_t cls = n <= HG_FIN_MEDIUM_CAP ? 0u : 1u;
+        big_list[cls * HG_FIN_MAX_BUCKETS + atomicAdd(big_count + cls, 1u)] = b;
+      }
       continue;
     }
     if (n == 0) {
@@ -1960,11 +1963,19 @@ __global__ __launch_bounds__(256) void hg_fin_sort_small_kernel(const HgHit *hit
     if (lane == 0) kept_count[b] = static_cast<uint32_t>(__popcll(km));
   }
 }
-// Larger buckets (hits clustered on few lines): one block sorts the bucket in LDS.
+// Larger buckets (hits clustered on few lines): one block sorts the bucket.  Two size classes, each with its own work list
+// and launch: nearly all larger buckets hold a few hundred records at most (LCAP = HG_FIN_MEDIUM_CAP, sorted in 6 KiB of
+// LDS); buckets of thousands of records are sorted in a scratch area in HBM (volatile accesses between block barriers: slow,
+// and rare) — with 48 KiB of LDS per block the launch waited 370-450 us for room next to the stream pass even when its
+// work list was empty.
+template <uint32_t LCAP, bool IN_LDS>
 __global__ __launch_bounds__(256) void hg_fin_sort_big_kernel(const HgHit *hits, uint32_t *idx, const uint32_t *fill, const uint32_t *big_list, const uint32_t *big_count,
-                                                              uint32_t cap, uint32_t id_bits, uint32_t to_bits, uint32_t *kept_count, uint32_t *overflow) {
-  __shared__ uint64_t s_key[HG_FIN_BUCKET_CAP];
-  __shared__ uint32_t s_idx[HG_FIN_BUCKET_CAP];
+                                                              uint32_t cap, uint32_t id_bits, uint32_t to_bits, uint32_t *kept_count, uint32_t *overflow, uint64_t *scratch_key,
+                                                              uint32_t *scratch_idx) {
+  __shared__ uint64_t l_key[IN_LDS ? LCAP : 1];
+  __shared__ uint32_t l_idx[IN_LDS ? LCAP : 1];
+  volatile uint64_t *s_key = IN_LDS ? l_key : scratch_key + static_cast<uint64_t>(blockIdx.x) * LCAP;
+  volatile uint32_t *s_idx = IN_LDS ? l_idx : scratch_idx + static_cast<uint64_t>(blockIdx.x) * LCAP;
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t group_shift = to_bits + 1;  // key >> group_shift == (line, id)
   const uint32_t nbig = *big_count;
@@ -1972,7 +1983,7 @@ __global__ __launch_bounds__(256) void hg_fin_sort_big_kernel(const HgHit *hits,
     const uint32_t b = big_list[q];
     uint32_t n = fill[b];
     if (n > cap) n = cap;
-    if (n > HG_FIN_BUCKET_CAP) {
+    if (n > LCAP) {  // (only the large class can meet this: beyond what one block sorts)
       if (tid == 0) {
         kept_count[b] = 0;
         atomicMax(overflow, n);
@@ -2032,9 +2043,13 @@ __global__ __launch_bounds__(256) void hg_fin_sort_big_kernel(const HgHit *hits,
     __syncthreads();
   }
 }
+template __global__ void hg_fin_sort_big_kernel<HG_FIN_MEDIUM_CAP, true>(const HgHit *, uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, uint32_t, uint32_t, uint32_t,
+                                                                          uint32_t *, uint32_t *, uint64_t *, uint32_t *);
+template __global__ void hg_fin_sort_big_kernel<HG_FIN_BUCKET_CAP, false>(const HgHit *, uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, uint32_t, uint32_t, uint32_t,
+                                                                           uint32_t *, uint32_t *, uint64_t *, uint32_t *);
 // One block: kept_count[b_lo, b_hi) -> exclusive positions in the compact output, continuing from *total (the kept records of
 // the bucket ranges finalized before); *total moves on.
-constexpr uint32_t HG_FIN_SCAN_THREADS = 1024;
+constexpr uint32_t HG_FIN_SCAN_THREADS = 512;  // (a block of 1024 does not fit on a CU next to two stream workgroups: it waited for the launch to end)
 __global__ __launch_bounds__(HG_FIN_SCAN_THREADS) void hg_fin_scan_kernel(uint32_t *kept_count, uint32_t b_lo, uint32_t b_hi, uint32_t *total, const uint32_t *fill,
                                                                           uint32_t cap) {
   // total[0] += kept records of the range, total[1] += raw records of the range (fill levels, a bucket holds at most cap)

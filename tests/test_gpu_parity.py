@@ -819,6 +819,26 @@ def test_skewed_hits_one_long_line_all_matches(torch_cuda):
 
 
 @pytest.mark.gpu
+def test_finalize_bucket_size_classes(torch_cuda):
+    """Hits clustered on a few lines: buckets of the finalize with a few hundred reports (sorted by one block in LDS), with
+    one to four thousand (sorted in a scratch area in HBM) and the ordinary ones (one wave, in registers) side by side;
+    several expressions share ids, SINGLEMATCH and all-matches mixed, duplicates by construction."""
+    rng = random.Random(73)
+    lines = [" ".join(rng.choice(["needle7", "foo", "x=1", "lorem", "needle8x"]) for _ in range(rng.randint(0, 8))) for _ in range(3000)]
+    lines[500] = " ".join("needle%d" % (i % 10) for i in range(300))
+    lines[1500] = " ".join("needle%d%s" % (i % 10, "x" * (i % 3)) for i in range(900))
+    lines[2500] = " ".join("needle7" for _ in range(1200))
+    data = ("\n".join(lines) + "\n").encode()
+    pats = ["needle[0-9]", "needle[0-9]x*", "foo", "needle7"]
+    flags = [6, 6, 14, 14]
+    ids = [0, 0, 2, 3]
+    want, nlines = oracle_hits(data, pats, flags, ids)
+    got, stats = gpu_scan_buffer(torch_cuda, data, pats, flags, ids)
+    assert stats.n_lines == nlines and got == want
+    assert len(want) > 8000 and stats.n_raw_hits > len(want)
+
+
+@pytest.mark.gpu
 def test_five_byte_literals_probe_every_second_byte(torch_cuda):
     """Every required literal of the set has >= 5 bytes: byte-aligned probing at even offsets only (two windows per literal,
     eight probes per 16 bytes).  Occurrences at every alignment, across rows, tiles and the end of the text, NULs, small buffers."""
