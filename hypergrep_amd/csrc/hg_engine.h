@@ -186,6 +186,7 @@ class HgScanner {
   HgHit *d_acc_hits_ = nullptr;  // segmented scans: the segments' ordered hits, one after the other
   HgHitAux *d_acc_aux_ = nullptr;
   uint64_t acc_cap_ = 0;
+  bool side_bound_ = false;  // the last piped pass: the side passes, not the stream launches, set the pace (no joiner, no finalize on the side stream)
   uint64_t *d_key_a_ = nullptr, *d_key_b_ = nullptr;
   uint32_t *d_perm_a_ = nullptr, *d_perm_b_ = nullptr;
   uint8_t *d_keep_ = nullptr;

@@ -351,12 +351,12 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
     // Joiners: the side passes of chunk c - 1 take about half as long as the stream pass of chunk c; behind them, on the side
     // stream, a second launch of the stream kernel (one more workgroup per CU, its own candidate segments) joins chunk c and
     // draws tiles from the same cursor until the chunk is used up.
-    // (Only where a CU has room for it: the kernel's LDS allows three workgroups per CU and the shared launches use two.
-    // When the side passes are the slower half — config 5 — the joiner finds the cursor used up and leaves at once.
+    // (Only where a CU has room for it: the kernel's LDS allows three workgroups per CU and the shared launches use two;
+    // and not when the last pass found the side passes to be the slower half (side_bound_: config 5).
     // Measured: 6.99 -> 6.84 ms per 32 GiB on config 3; HG_JOINER=0 turns it off.)
     // Not for texts so dense in candidates that the chunks had to shrink: their side passes are the slower half anyway, and
     // the joiner's segments would take workspace from the others.
-    uint32_t joiner_wgs = (piped && stream_wgs_per_cu_ >= 3 && per_cu < static_cast<uint32_t>(stream_wgs_per_cu_) && chunk_limit_tiles_ == 0) ? static_cast<uint32_t>(num_cus_) : 0u;
+    uint32_t joiner_wgs = (piped && stream_wgs_per_cu_ >= 3 && per_cu < static_cast<uint32_t>(stream_wgs_per_cu_) && chunk_limit_tiles_ == 0 && !side_bound_) ? static_cast<uint32_t>(num_cus_) : 0u;
     if (const char *env = std::getenv("HG_JOINER")) joiner_wgs = piped ? static_cast<uint32_t>(std::max(0l, std::min(2l, std::strtol(env, nullptr, 10)))) * static_cast<uint32_t>(num_cus_) : 0u;
     if (wgs_shared + joiner_wgs > max_segs_) joiner_wgs = 0;
     wgs = std::max(wgs_shared + joiner_wgs, wgs_alone);  // sizes the regrowth of the candidate segments
@@ -365,7 +365,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       for (int i = 0; i < kMaxChunks; i++) {
         HG_TRY(hipEventCreate(&ev_k1_begin_[i]), "hipEventCreate");
         HG_TRY(hipEventCreate(&ev_k1_end_[i]), "hipEventCreate");
-        HG_TRY(hipEventCreateWithFlags(&ev_side_done_[i], hipEventDisableTiming), "hipEventCreate");
+        HG_TRY(hipEventCreate(&ev_side_done_[i]), "hipEventCreate");  // (timed: which of stream pass / side passes ends later, below)
       }
     }
     if (piped) {  // side stream starts after the counters / state are in place
@@ -579,6 +579,14 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       (void)hipEventElapsedTime(&ms, ev_k1_begin_[c], ev_k1_end_[c]);
       out->ms_stream += ms;
     }
+    // Which half of the pipeline set the pace: did the side passes of chunk c - 1 end after the stream launch of chunk c?
+    // (config 5: yes — 42 M candidates per pass.)  Then the side stream has no idle window for the next pass to use.
+    uint32_t late = 0;
+    for (uint32_t c = 1; c < nchunks; c++) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, ev_k1_end_[c], ev_side_done_[c - 1]) == hipSuccess && ms > 0) late++;
+    }
+    side_bound_ = late * 2 > nchunks - 1;
   }
 
   const uint64_t n_cands = h_counters_[HG_CNT_CANDS];
