@@ -178,7 +178,10 @@ def main() -> None:
         # the streaming kernel is launched once per pipeline chunk (8 GiB chunks at 32 GiB): all figures are PER LAUNCH
         launches = max(last.stream_launches, 1)
         stream_ms = sum(ms_stream) / len(ms_stream) / launches
-        algo_bytes = (nbytes + 16 * last.n_hits) // launches  # 1 B read per text byte + 16 B written per hit
+        # 1 B read per text byte + 16 B written per hit.  The text bytes of the tiles that the joiner launches
+        # streamed (hg_stream_join_kernel, counted by the kernel) are not these launches' work.
+        joined_bytes = last.joiner_tiles * 16384
+        algo_bytes = (nbytes - joined_bytes + 16 * last.n_hits) // launches
         achieved = algo_bytes / (stream_ms * 1e-3) / 1e9
         out = {
             "metric": "GiB/s scanned (256 patterns, 32 GiB synthetic log per GPU, text resident in HBM)",
@@ -201,6 +204,7 @@ def main() -> None:
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": "hg_stream_kernel",
                          "kernel_ms": round(stream_ms, 4), "algorithmic_bytes": algo_bytes, "launches_per_step": launches,
+                         "joiner": {"kernel": "hg_stream_join_kernel", "launches_per_step": last.joiner_launches, "text_bytes_per_step": joined_bytes},
                          # the whole launch sequence of a step (SURVEY.md §8d t_kernels) priced the same way: all algorithmic bytes / step time
                          "pipeline_frac": round((nbytes + 16 * last.n_hits) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
             "pipeline": {"candidates": last.n_candidates, "raw_hits": last.n_raw_hits, "reruns": last.reruns,

@@ -111,6 +111,9 @@ int hg_scan_device(hg_scanner_t *scanner, const void *d_text, uint64_t nbytes, i
   result->ms_total = o.ms_total;
   result->reruns = o.reruns;
   result->stream_launches = o.stream_launches;
+  result->joiner_tiles = o.joiner_tiles;
+  result->joiner_launches = o.joiner_launches;
+  result->reserved = 0;
   scanner->last = *result;
   return HG_OK;
 }

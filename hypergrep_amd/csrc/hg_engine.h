@@ -33,6 +33,7 @@ enum { HG_ST_FIN_TOTAL = 24, HG_ST_SELECTED = 28, HG_ST_FINAL = 32, HG_ST_WORDS 
        HG_ST_BLOCK_DONE = 40 };  // (outside the words a pass resets: workgroups of hg_block_small_kernel that have finished)
 enum { HG_CNT_CANDS = 0, HG_CNT_HITS = 1, HG_CNT_CAND_NEED = 2, HG_CNT_HIT_NEED = 3, HG_CNT_DEFER_NEED = 4,
        HG_CNT_HITS_WRAPPED = 5,  // the 32-bit hit counter went round (direct appends): the buffer is scanned in segments instead
+       HG_CNT_JOIN_TILES = 6,  // tiles taken by the joiner launches of the pass (hg_stream_join_kernel)
        HG_CNT_WORDS = 8,
        HG_CNT_CURSOR0 = 8,      // one tile cursor per pipeline chunk follows the counters proper
        HG_CNT_ALL_WORDS = 8 + 16 };
@@ -120,6 +121,8 @@ struct HgScanOutput {
   float ms_total;        // whole launch sequence
   uint32_t reruns;       // workspace grew and the pass was repeated this many times
   uint32_t stream_launches;  // hg_stream_kernel launches of the (last) pass: one per pipeline chunk
+  uint32_t joiner_launches;  // ... and hg_stream_join_kernel launches
+  uint64_t joiner_tiles;     // tiles (of 16 KiB) the joiner launches took: bytes the hg_stream_kernel launches did NOT stream
 };
 
 class HgScanner {

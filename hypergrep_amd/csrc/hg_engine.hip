@@ -14,6 +14,7 @@
 
 // kernels (hg_kernels.hip)
 bool hg_launch_stream(const HgStreamArgs &a, uint32_t grid, hipStream_t stream);
+bool hg_launch_stream_join(const HgStreamArgs &a, uint32_t grid, hipStream_t stream);
 int hg_stream_blocks_per_cu(uint32_t filter_log2, uint32_t filter_wide, uint32_t dense);
 __global__ void hg_tile_reduce_kernel(const HgTileSum *sums, uint64_t tile_begin, uint64_t tile_end, uint64_t bs1, HgTileElem *agg);
 __global__ void hg_tile_spine_kernel(const HgTileElem *agg, uint32_t nblocks, uint64_t bs1, HgTileBase *block_base, HgTileBase *state);
@@ -334,6 +335,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   uint32_t wgs = 1, confirm_blocks = 1, always_blocks = 1;
   out->ms_stream = 0;
   out->stream_launches = ntiles ? nchunks : 0;
+  out->joiner_launches = 0;
   if (ntiles) {
     if (stream_wgs_per_cu_ == 0) stream_wgs_per_cu_ = hg_stream_blocks_per_cu(db_->filter_log2, db_->filter_wide, db_->dense);
     uint32_t per_cu = piped ? std::max(1, stream_wgs_per_cu_ - 1) : stream_wgs_per_cu_;
@@ -358,7 +360,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
     // the joiner's segments would take workspace from the others.
     uint32_t joiner_wgs = (piped && stream_wgs_per_cu_ >= 3 && per_cu < static_cast<uint32_t>(stream_wgs_per_cu_) && chunk_limit_tiles_ == 0 && !side_bound_) ? static_cast<uint32_t>(num_cus_) : 0u;
     if (const char *env = std::getenv("HG_JOINER")) joiner_wgs = piped ? static_cast<uint32_t>(std::max(0l, std::min(2l, std::strtol(env, nullptr, 10)))) * static_cast<uint32_t>(num_cus_) : 0u;
-    if (wgs_shared + joiner_wgs > max_segs_) joiner_wgs = 0;
+    if (wgs_shared + joiner_wgs > max_segs_ || db_->filter_wide || db_->filter_log2 > 13) joiner_wgs = 0;  // (hg_launch_stream_join's instantiations)
     wgs = std::max(wgs_shared + joiner_wgs, wgs_alone);  // sizes the regrowth of the candidate segments
     hipStream_t side = piped ? side_stream_ : stream;
     if (piped && !ev_side_done_[0]) {
@@ -451,7 +453,8 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
         ja.cands = cands + static_cast<uint64_t>(wgs_c) * sa.cand_seg_cap;
         ja.seg_count = seg_count + wgs_c;
         ja.alone = 0;
-        if (!hg_launch_stream(ja, joiners_c, side)) return HG_ERR_ARG;
+        if (!hg_launch_stream_join(ja, joiners_c, side)) return HG_ERR_ARG;
+        out->joiner_launches++;
         HG_TRY(hipGetLastError(), "hg_stream_kernel launch (joiner)");
       }
       if (piped) HG_TRY(hipStreamWaitEvent(side, ev_k1_end_[c], 0), "stream wait");
@@ -589,6 +592,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
     side_bound_ = late * 2 > nchunks - 1;
   }
 
+  out->joiner_tiles = h_counters_[HG_CNT_JOIN_TILES];
   const uint64_t n_cands = h_counters_[HG_CNT_CANDS];
   const uint64_t n_raw = bucketed ? h_counters_[HG_ST_FIN_TOTAL + 1] : h_counters_[HG_CNT_HITS];
   const uint64_t cand_need = h_counters_[HG_CNT_CAND_NEED], hit_need = h_counters_[HG_CNT_HIT_NEED];
@@ -803,7 +807,8 @@ int HgScanner::scan_segments(const uint8_t *text, uint64_t nbytes, uint64_t bs1,
   fin_fallback_ = false;  // (a smaller stretch: bucketed emission gets another chance)
   fin_expect_hits_ /= nsegments;
   uint64_t acc = 0, cands = 0, raw = 0, cs0 = 0, piece0 = line_base;
-  uint32_t reruns = 0, launches = 0;
+  uint32_t reruns = 0, launches = 0, join_launches = 0;
+  uint64_t join_tiles = 0;
   float ms_stream = 0, ms_total = 0;
   HgScanOutput part{};
   for (uint64_t lo = 0; lo < ntiles; lo += seg_tiles) {
@@ -859,6 +864,8 @@ int HgScanner::scan_segments(const uint8_t *text, uint64_t nbytes, uint64_t bs1,
     ms_stream += part.ms_stream;
     ms_total += part.ms_total;
     launches += part.stream_launches;
+    join_launches += part.joiner_launches;
+    join_tiles += part.joiner_tiles;
     if (!last) {  // the tile-scan state at the next segment's first tile (this pass has scanned past it)
       HgTileBase next{};
       if (fail(hipMemcpyAsync(&next, d_bases_ + (lo + seg_tiles), sizeof next, hipMemcpyDeviceToHost, stream), "copy") || fail(hipStreamSynchronize(stream), "sync")) return HG_ERR_HIP;
@@ -877,5 +884,7 @@ int HgScanner::scan_segments(const uint8_t *text, uint64_t nbytes, uint64_t bs1,
   out->ms_total = ms_total;
   out->reruns = reruns;
   out->stream_launches = launches;
+  out->joiner_launches = join_launches;
+  out->joiner_tiles = join_tiles;
   return HG_OK;
 }

@@ -507,12 +507,12 @@ __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, 
 #endif
 // DEPTH: 16-byte loads in flight per lane.  With non-temporal loads three is best for both kinds of launch (before, a launch
 // that had three workgroups per CU to itself did better with one: deeper prefetch thrashed the L2).
-template <int LOG2, bool WIDE, int DENSE, int DEPTH>
-__global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_STREAM_WAVES, 8))) void hg_stream_kernel(const uint4 *__restrict__ text16, uint64_t nbytes, uint64_t tile_begin, uint64_t tile_end,
-                                                                  const uint4 *__restrict__ filter16, const uint4 *__restrict__ ext16,
-                                                                  uint32_t fold, uint32_t wa, uint32_t wb, HgTileSum *__restrict__ sums,
-                                                                  HgCand *__restrict__ cands, uint32_t seg_cap,
-                                                                  uint32_t *__restrict__ seg_count, uint32_t *__restrict__ counters, uint32_t cursor_slot) {
+// JOIN: the launch that joins a chunk behind the previous chunk's side passes (hg_stream_join_kernel, same code under its
+// own name so that profiles keep the two kinds of launch apart); it also counts the tiles it took (HG_CNT_JOIN_TILES).
+template <int LOG2, bool WIDE, int DENSE, int DEPTH, bool JOIN>
+__device__ __forceinline__ void stream_body(const uint4 *__restrict__ text16, uint64_t nbytes, uint64_t tile_begin, uint64_t tile_end, const uint4 *__restrict__ filter16,
+                                            const uint4 *__restrict__ ext16, uint32_t fold, uint32_t wa, uint32_t wb, HgTileSum *__restrict__ sums, HgCand *__restrict__ cands,
+                                            uint32_t seg_cap, uint32_t *__restrict__ seg_count, uint32_t *__restrict__ counters, uint32_t cursor_slot) {
   // LDS, one block so that the filter starts at offset 0 (its byte offsets then fold into the ds_read instructions):
   //   window hash slots (4 B each) | per-wave chunk queues | candidate counter
   constexpr uint32_t FILTER_U4 = (4u << LOG2) / 16, QUEUE_U4 = WG_WAVES * queue_cap(LOG2) * queue_entry_dw(LOG2, DENSE) * 4 / 16;
@@ -541,12 +541,12 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_S
   // (counters[cursor_slot], one atomic per run).  A run is consecutive in the text, so a segment's candidates cluster (the verify / confirm passes touch
   // neighbouring lines from neighbouring lanes).  Dealing the tiles out on demand instead of giving every workgroup a fixed
   // range took the pass from 73 % to 82 % of the HBM peak on an 8 GiB launch: no workgroup waits at the end for the slowest.
-  // (A second launch that joins a chunk late — a third workgroup per CU once the previous chunk's side passes have left —
-  // was tried on top of this and lost 2-3 %: its workgroups arrive for the last fifth of the chunk and mostly pay start-up.)
+  // (A second launch joins a chunk late — a third workgroup per CU once the previous chunk's side passes have left: JOIN.
+  // It lost 2-3 % while those passes took most of a stream launch, and pays since the confirm pass runs on windows.)
   lds_u32 *s_run = cx.cand_count + 1;  // (the dword next to the candidate counter: one LDS block, the filter stays at offset 0)
   const uint32_t ntile = static_cast<uint32_t>(tile_end - tile_begin);  // (tile numbers relative to the chunk: 32-bit scalars)
   const uint32_t nfull = full_tiles > tile_begin ? static_cast<uint32_t>(full_tiles - tile_begin < ntile ? full_tiles - tile_begin : ntile) : 0u;
-  uint32_t qn = 0;
+  uint32_t qn = 0, joined = 0;
   for (;;) {
     if (threadIdx.x == 0) *s_run = atomicAdd(&counters[cursor_slot], HG_STREAM_GRAB);
     __syncthreads();
@@ -554,6 +554,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_S
     __syncthreads();                                              // read by every wave before the next draw overwrites it
     if (r0 >= ntile) break;
     const uint32_t r1 = r0 + HG_STREAM_GRAB < ntile ? r0 + HG_STREAM_GRAB : ntile;
+    if (JOIN) joined += r1 - r0;
     for (uint32_t r = r0 + wave; r < r1; r += WG_WAVES) {
       if (r < nfull) stream_tile<LOG2, WIDE, DENSE, true, DEPTH>(cx, tile_begin + r, sums, lane, qn);
       else stream_tile<LOG2, WIDE, DENSE, false, DEPTH>(cx, tile_begin + r, sums, lane, qn);
@@ -566,7 +567,22 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_S
     seg_count[blockIdx.x] = n < seg_cap ? n : seg_cap;
     atomicAdd(&counters[HG_CNT_CANDS], n < seg_cap ? n : seg_cap);
     if (n > seg_cap) atomicMax(&counters[HG_CNT_CAND_NEED], n);
+    if (JOIN && joined) atomicAdd(&counters[HG_CNT_JOIN_TILES], joined);
   }
+}
+template <int LOG2, bool WIDE, int DENSE, int DEPTH>
+__global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_STREAM_WAVES, 8))) void hg_stream_kernel(
+    const uint4 *__restrict__ text16, uint64_t nbytes, uint64_t tile_begin, uint64_t tile_end, const uint4 *__restrict__ filter16, const uint4 *__restrict__ ext16, uint32_t fold,
+    uint32_t wa, uint32_t wb, HgTileSum *__restrict__ sums, HgCand *__restrict__ cands, uint32_t seg_cap, uint32_t *__restrict__ seg_count, uint32_t *__restrict__ counters,
+    uint32_t cursor_slot) {
+  stream_body<LOG2, WIDE, DENSE, DEPTH, false>(text16, nbytes, tile_begin, tile_end, filter16, ext16, fold, wa, wb, sums, cands, seg_cap, seg_count, counters, cursor_slot);
+}
+template <int LOG2, int DENSE>  // (only where three workgroups fit on a CU: filters of up to 32 KiB, single-probe mode)
+__global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_STREAM_WAVES, 8))) void hg_stream_join_kernel(
+    const uint4 *__restrict__ text16, uint64_t nbytes, uint64_t tile_begin, uint64_t tile_end, const uint4 *__restrict__ filter16, const uint4 *__restrict__ ext16, uint32_t fold,
+    uint32_t wa, uint32_t wb, HgTileSum *__restrict__ sums, HgCand *__restrict__ cands, uint32_t seg_cap, uint32_t *__restrict__ seg_count, uint32_t *__restrict__ counters,
+    uint32_t cursor_slot) {
+  stream_body<LOG2, false, DENSE, HG_DEPTH_SHARED, true>(text16, nbytes, tile_begin, tile_end, filter16, ext16, fold, wa, wb, sums, cands, seg_cap, seg_count, counters, cursor_slot);
 }
 
 // Host-side launcher: picks the instantiation for the database's filter size / mode.
@@ -593,6 +609,32 @@ int blocks_one() {
   return n > 0 ? n : 1;
 }
 }  // namespace
+namespace {
+template <int L, int B>
+void launch_join(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
+  hipLaunchKernelGGL((hg_stream_join_kernel<L, B>), dim3(grid), dim3(WG_THREADS), 0, stream, reinterpret_cast<const uint4 *>(a.text), a.nbytes, a.tile_begin, a.tile_end,
+                     reinterpret_cast<const uint4 *>(a.filter), reinterpret_cast<const uint4 *>(a.ext), a.db.fold_mask, a.weights_a, a.dense ? a.weights_c : a.weights_b, a.sums,
+                     a.cands, a.cand_seg_cap, a.seg_count, a.counters, a.cursor_slot);
+}
+}  // namespace
+// The joiner launch (hg_engine.hip).  false: no such instantiation (wide filters, filters beyond 32 KiB: no room for a third
+// workgroup on a CU anyway).
+bool hg_launch_stream_join(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
+  if (a.filter_wide || a.filter_log2 < 11 || a.filter_log2 > 13 || a.dense > 2) return false;
+  switch (a.filter_log2 * 4 + a.dense) {
+    case 11 * 4 + 0: launch_join<11, 0>(a, grid, stream); break;
+    case 11 * 4 + 1: launch_join<11, 1>(a, grid, stream); break;
+    case 11 * 4 + 2: launch_join<11, 2>(a, grid, stream); break;
+    case 12 * 4 + 0: launch_join<12, 0>(a, grid, stream); break;
+    case 12 * 4 + 1: launch_join<12, 1>(a, grid, stream); break;
+    case 12 * 4 + 2: launch_join<12, 2>(a, grid, stream); break;
+    case 13 * 4 + 0: launch_join<13, 0>(a, grid, stream); break;
+    case 13 * 4 + 1: launch_join<13, 1>(a, grid, stream); break;
+    case 13 * 4 + 2: launch_join<13, 2>(a, grid, stream); break;
+    default: return false;
+  }
+  return true;
+}
 // Returns false when no instantiation exists for the database's (filter size, mode): nothing was launched.
 bool hg_launch_stream(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
   if (a.filter_wide) {

@@ -26,6 +26,7 @@ class HgScanResult(ctypes.Structure):
         ("n_hits", ctypes.c_uint64), ("n_lines", ctypes.c_uint64), ("n_candidates", ctypes.c_uint64),
         ("n_raw_hits", ctypes.c_uint64), ("d_hits", ctypes.c_void_p), ("d_aux", ctypes.c_void_p),
         ("ms_stream", ctypes.c_float), ("ms_total", ctypes.c_float), ("reruns", ctypes.c_uint32), ("stream_launches", ctypes.c_uint32),
+        ("joiner_tiles", ctypes.c_uint64), ("joiner_launches", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
     ]
 
 
@@ -121,6 +122,8 @@ class ScanStats:
     ms_total: float
     reruns: int
     stream_launches: int = 1
+    joiner_launches: int = 0
+    joiner_tiles: int = 0
 
 
 class Scanner:
@@ -141,7 +144,7 @@ class Scanner:
         if rc != 0:
             raise DeviceError(f"hg_scan_device failed ({rc}): {lib().hg_scanner_error(self._h).decode(errors='replace')}")
         self._last = res
-        return ScanStats(res.n_hits, res.n_lines, res.n_candidates, res.n_raw_hits, res.ms_stream, res.ms_total, res.reruns, res.stream_launches)
+        return ScanStats(res.n_hits, res.n_lines, res.n_candidates, res.n_raw_hits, res.ms_stream, res.ms_total, res.reruns, res.stream_launches, res.joiner_launches, res.joiner_tiles)
 
     @property
     def d_hits(self) -> int:

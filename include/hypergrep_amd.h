@@ -144,6 +144,9 @@ typedef struct hg_scan_result {
     float ms_total;  /* whole launch sequence */
     uint32_t reruns; /* passes repeated because the workspace had to grow */
     uint32_t stream_launches; /* launches of the streaming kernel in this scan (one per pipeline chunk) */
+    uint64_t joiner_tiles;    /* 16 KiB tiles streamed by the joiner launches (hg_stream_join_kernel), not by those */
+    uint32_t joiner_launches; /* launches of the joiner kernel in this scan */
+    uint32_t reserved;
 } hg_scan_result_t;
 
 typedef struct hg_db_info {

@@ -22,7 +22,7 @@ for name in ("FETCH_SIZE", "WRITE_SIZE"):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != name: continue
             k = r["Kernel_Name"]
-            k = "hg_stream_kernel" if "hg_stream" in k else ("hg_verify_kernel" if "hg_verify" in k else ("hg_confirm*" if "hg_confirm" in k else None))
+            k = "hg_stream_join_kernel" if "hg_stream_join" in k else "hg_stream_kernel" if "hg_stream" in k else ("hg_verify_kernel" if "hg_verify" in k else ("hg_confirm*" if "hg_confirm" in k else None))
             if not k: continue
             agg[k][0] += 1; agg[k][1] += float(r["Counter_Value"])
     for k, (n, v) in sorted(agg.items()):
