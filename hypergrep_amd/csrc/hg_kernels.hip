@@ -939,6 +939,10 @@ __global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
   if (threadIdx.x == 0) s_stage.n = 0;
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#ifdef HG_PROFILE_CONFIRM
+  const uint64_t pf_t0 = wall_clock64();
+  uint32_t pf_rounds = 0, pf_pairs = 0;
+#endif
   const uint32_t seg = blockIdx.x / HG_CONFIRM_SPLIT, sub = blockIdx.x % HG_CONFIRM_SPLIT;
   const HgCand *cseg = a.cands + static_cast<uint64_t>(seg) * a.cand_seg_cap;
   uint32_t n = a.seg_count[seg];
@@ -989,6 +993,10 @@ __global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
     }
     const uint32_t incl = wave_inclusive_scan(cnt, lane), start = incl - cnt;
     const uint32_t total = __shfl(incl, 63, 64);
+#ifdef HG_PROFILE_CONFIRM
+    pf_rounds++;
+    pf_pairs += total;
+#endif
     const uint32_t pos_lo = static_cast<uint32_t>(c.pos), pos_hi = static_cast<uint32_t>(c.pos >> 32);
     for (uint32_t t0 = 0; t0 < total; t0 += 64) {  // wave-uniform
       const uint32_t t = t0 + lane;
@@ -1073,7 +1081,13 @@ __global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
       }
     }
   }
+#ifdef HG_PROFILE_CONFIRM
+  const uint64_t pf_t1 = wall_clock64();
+#endif
   verify_stage_flush(a, s_stage);
+#ifdef HG_PROFILE_CONFIRM
+  if (lane == 0) a.tmp_hits[(6u << 20) + 65536u + blockIdx.x * 4u + wave] = HgHit{pf_t0, static_cast<uint32_t>(wall_clock64() - pf_t0), pf_rounds | (pf_pairs << 8) | (static_cast<uint32_t>(pf_t1 - pf_t0) > 0xFFFFu ? 0u : 0u)};
+#endif
 }
 
 // Confirm passes over the lists of verified occurrences, one routine per confirm mode so that the lanes of a wave do the

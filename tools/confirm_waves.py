@@ -46,3 +46,12 @@ for m in (1, 2):
     if not len(r): continue
     load = (r["ls"] & 0xFFFFFFFF) / 100.0; stage = (r["ls"] >> 32) / 100.0; run = r["run"] / 100.0; pats = r["tag"] & 0xFFFFFFF
     print(f"mode {m}: busy waves {len(r)}: load us mean {load.mean():.1f} max {load.max():.1f}; stage mean {stage.mean():.1f} max {stage.max():.1f}; run mean {run.mean():.1f} p90 {np.percentile(run,90):.1f} max {run.max():.1f}; patterns per wave mean {pats.mean():.2f} max {pats.max()}")
+
+nv = 12288 * 2
+raw3 = ctypes.create_string_buffer(nv * 16)
+assert device.lib().hg_debug_download(raw3, ctypes.c_void_p(sc._last.d_hits + ((6 << 20) + 65536) * 16), nv * 16) == 0
+r3 = np.frombuffer(raw3.raw, dtype=np.dtype([("t0", "<u8"), ("dur", "<u4"), ("tag", "<u4")]))
+r3 = r3[r3["t0"] > 0]
+if len(r3):
+    v0 = r3["t0"].min(); d = r3["dur"] / 100.0; st = (r3["t0"] - v0) / 100.0; rounds = r3["tag"] & 0xFF; pairs = r3["tag"] >> 8
+    print(f"verify: waves {len(r3)} span us {(st + d).max():.1f}; dur mean {d.mean():.1f} p50 {np.percentile(d,50):.1f} p90 {np.percentile(d,90):.1f} max {d.max():.1f}; start p50 {np.percentile(st,50):.1f} p90 {np.percentile(st,90):.1f} max {st.max():.1f}; rounds per wave mean {rounds.mean():.2f} max {rounds.max()}; pairs per wave mean {pairs.mean():.1f} max {pairs.max()}")
