@@ -38,6 +38,7 @@ __global__ void hg_fin_sort_small_kernel(const HgHit *hits, uint32_t *idx, const
 template <uint32_t LCAP, bool IN_LDS>
 __global__ void hg_fin_sort_big_kernel(const HgHit *hits, uint32_t *idx, const uint32_t *fill, const uint32_t *big_list, const uint32_t *big_count, uint32_t cap,
                                        uint32_t id_bits, uint32_t to_bits, uint32_t *kept_count, uint32_t *overflow, uint64_t *scratch_key, uint32_t *scratch_idx);
+template <uint32_t THREADS>
 __global__ void hg_fin_scan_kernel(uint32_t *kept_count, uint32_t b_lo, uint32_t b_hi, uint32_t *total, const uint32_t *fill, uint32_t cap);
 __global__ void hg_fin_gather_kernel(const HgHit *hits, const HgHitAux *aux, const uint32_t *idx, const uint32_t *kept_base, const uint32_t *total, uint32_t b_lo,
                                      uint32_t b_hi, uint32_t cap, HgHit *oh, HgHitAux *oa);
@@ -375,7 +376,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       HG_TRY(hipStreamWaitEvent(side, ev_side_done_[kMaxChunks - 1], 0), "stream wait");
     }
     // finalize of the buckets [lo, hi) on stream `s`: order each bucket, report rules, positions, gather (hg_fin_*)
-    auto launch_fin = [&](hipStream_t s, uint32_t lo, uint32_t hi) -> int {
+    auto launch_fin = [&](hipStream_t s, uint32_t lo, uint32_t hi, bool beside_stream = false) -> int {
       if (hi <= lo) return HG_OK;
       const uint32_t nbk = hi - lo, cu = static_cast<uint32_t>(num_cus_);
       HG_TRY(hipMemsetAsync(d_fin_total_ + 2, 0, 8, s), "memset work list");  // (larger buckets of this range: two size classes)
@@ -388,7 +389,8 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       if (big_blocks)
         hipLaunchKernelGGL((hg_fin_sort_big_kernel<HG_FIN_BUCKET_CAP, false>), dim3(big_blocks), dim3(256), 0, s, d_hits_raw_, d_perm_a_, d_fin_fill_, d_fin_big_ + HG_FIN_MAX_BUCKETS,
                            d_fin_total_ + 3, fin_cap, id_bits, to_bits, d_fin_kept_, d_selected_ + 1, d_key_a_, d_perm_b_);
-      hipLaunchKernelGGL(hg_fin_scan_kernel, dim3(1), dim3(512), 0, s, d_fin_kept_, lo, hi, d_fin_total_, d_fin_fill_, fin_cap);
+      if (beside_stream) hipLaunchKernelGGL(hg_fin_scan_kernel<512u>, dim3(1), dim3(512), 0, s, d_fin_kept_, lo, hi, d_fin_total_, d_fin_fill_, fin_cap);
+      else hipLaunchKernelGGL(hg_fin_scan_kernel<1024u>, dim3(1), dim3(1024), 0, s, d_fin_kept_, lo, hi, d_fin_total_, d_fin_fill_, fin_cap);
       hipLaunchKernelGGL(hg_fin_gather_kernel, dim3(std::min<uint32_t>((nbk + 3) / 4, cu * 8)), dim3(256), 0, s, d_hits_raw_, d_aux_raw_, d_perm_a_, d_fin_kept_, d_fin_total_, lo, hi, fin_cap,
                          d_hits_out_, d_aux_out_);
       HG_TRY(hipGetLastError(), "finalize launch");
@@ -444,7 +446,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
         const uint64_t settled = prev_end > bs1 ? prev_end - bs1 : 0;
         const uint32_t lim = static_cast<uint32_t>(std::min<uint64_t>((settled > range.own_lo ? settled - range.own_lo : 0) >> fin_shift, fin_nb));
         if (lim > fin_done) {
-          if (int rc = launch_fin(side, fin_done, lim)) return rc;
+          if (int rc = launch_fin(side, fin_done, lim, true)) return rc;
           fin_done = lim;
         }
       }

@@ -2105,7 +2105,9 @@ template __global__ void hg_fin_sort_big_kernel<HG_FIN_BUCKET_CAP, false>(const 
                                                                            uint32_t *, uint32_t *, uint64_t *, uint32_t *);
 // One block: kept_count[b_lo, b_hi) -> exclusive positions in the compact output, continuing from *total (the kept records of
 // the bucket ranges finalized before); *total moves on.
-constexpr uint32_t HG_FIN_SCAN_THREADS = 512;  // (a block of 1024 does not fit on a CU next to two stream workgroups: it waited for the launch to end)
+// (THREADS: 1024 when the finalize has the chip to itself or shares it with side passes; 512 beside the stream pass, where a
+// block of 1024 does not fit on a CU next to two stream workgroups and waited for the launch to end)
+template <uint32_t HG_FIN_SCAN_THREADS>
 __global__ __launch_bounds__(HG_FIN_SCAN_THREADS) void hg_fin_scan_kernel(uint32_t *kept_count, uint32_t b_lo, uint32_t b_hi, uint32_t *total, const uint32_t *fill,
                                                                           uint32_t cap) {
   // total[0] += kept records of the range, total[1] += raw records of the range (fill levels, a bucket holds at most cap)
@@ -2151,6 +2153,8 @@ __global__ __launch_bounds__(HG_FIN_SCAN_THREADS) void hg_fin_scan_kernel(uint32
     total[1] += all_raw;
   }
 }
+template __global__ void hg_fin_scan_kernel<512u>(uint32_t *, uint32_t, uint32_t, uint32_t *, const uint32_t *, uint32_t);
+template __global__ void hg_fin_scan_kernel<1024u>(uint32_t *, uint32_t, uint32_t, uint32_t *, const uint32_t *, uint32_t);
 // kept records of bucket b (idx[b * cap ...] in final order) -> out[kept_base[b] ...]; bucket b + 1's base (or *total for the
 // last bucket of the range) ends the run.  One wave per bucket, grid-stride.
 __global__ void hg_fin_gather_kernel(const HgHit *hits, const HgHitAux *aux, const uint32_t *idx, const uint32_t *kept_base, const uint32_t *total, uint32_t b_lo,
