@@ -634,23 +634,76 @@ bool has_assert(const Node &n) {
 }
 
 // ---------------------------------------------------------------- position automaton
+// Contexts in which the expression matches the empty string (a 20-bit truth table, HG_TT_ALL = always).
+uint32_t nullable_tt(const Node &n) {
+  switch (n.kind) {
+    case Node::Empty: return HG_TT_ALL;
+    case Node::Assert: return n.tt;
+    case Node::Class: return 0;
+    case Node::Cat: {
+      uint32_t t = HG_TT_ALL;
+      for (auto &k : n.kids) t &= nullable_tt(*k);
+      return t;
+    }
+    case Node::Alt: {
+      uint32_t t = 0;
+      for (auto &k : n.kids) t |= nullable_tt(*k);
+      return t;
+    }
+    case Node::Rep: return (n.min == 0 || n.kids.empty()) ? HG_TT_ALL : nullable_tt(*n.kids[0]);
+  }
+  return 0;
+}
+
+// Size of the expression as a Thompson program (one instruction per class / assertion, two per alternation branch point,
+// a split per optional copy, split + jump per loop): the measure Hyperscan's graph limits and the oracle (orx.c gen())
+// bound an expression by.  Saturates.
+uint64_t program_size(const Node &n) {
+  const uint64_t kCap = uint64_t(1) << 40;
+  switch (n.kind) {
+    case Node::Empty: return 0;
+    case Node::Class: case Node::Assert: return 1;
+    case Node::Cat: {
+      uint64_t t = 0;
+      for (auto &k : n.kids) t = std::min(kCap, t + program_size(*k));
+      return t;
+    }
+    case Node::Alt: {
+      if (n.kids.size() == 1) return program_size(*n.kids[0]);
+      uint64_t t = 2 * (n.kids.size() - 1);
+      for (auto &k : n.kids) t = std::min(kCap, t + program_size(*k));
+      return t;
+    }
+    case Node::Rep: {
+      const uint64_t k = program_size(*n.kids[0]);
+      const uint64_t opt = n.max < 0 ? k + 2 : static_cast<uint64_t>(n.max - n.min) * (k + 1);
+      return std::min(kCap, static_cast<uint64_t>(n.min) * k + opt);
+    }
+  }
+  return 0;
+}
+
 struct Cond { uint32_t pos, tt; };
 struct Frag {
   uint32_t nullable = 0;  // contexts in which the fragment matches the empty string
   std::vector<Cond> first, last;
 };
+struct Edge { uint32_t p, q, tt; };
 
+// Fragments own their position sets and are consumed (moved) by the combinators: every position belongs to exactly one
+// fragment at a time, so first / last sets only ever grow by appending, and an expression of n positions costs O(n + edges)
+// whatever its repeat counts (a{32767}: 32767 positions, 32766 edges).
 class Glushkov {
  public:
   std::vector<ByteSet> pos_class;
-  std::map<std::pair<uint32_t, uint32_t>, uint32_t> edges;  // (p, q) -> tt
+  std::vector<Edge> edges;  // (p, q, tt), possibly repeated: the table builder merges them
 
   Frag build(const Node &n) {
     switch (n.kind) {
       case Node::Empty: { Frag f; f.nullable = HG_TT_ALL; return f; }
       case Node::Assert: { Frag f; f.nullable = n.tt; return f; }
       case Node::Class: {
-        if (pos_class.size() >= HG_MAX_NODES) throw CompileError("pattern too large");
+        if (pos_class.size() >= HG_HUGE_MAX_NODES) throw CompileError("pattern too large");
         uint32_t p = static_cast<uint32_t>(pos_class.size());
         pos_class.push_back(n.cls);
         Frag f;
@@ -661,33 +714,45 @@ class Glushkov {
       case Node::Cat: {
         Frag acc;
         acc.nullable = HG_TT_ALL;
-        for (auto &k : n.kids) acc = cat(acc, build(*k));
+        for (auto &k : n.kids) acc = cat(std::move(acc), build(*k));
         return acc;
       }
       case Node::Alt: {
         Frag acc = build(*n.kids[0]);
-        for (size_t i = 1; i < n.kids.size(); i++) acc = alt(acc, build(*n.kids[i]));
+        for (size_t i = 1; i < n.kids.size(); i++) acc = alt(std::move(acc), build(*n.kids[i]));
         return acc;
       }
       case Node::Rep: {
         const Node &k = *n.kids[0];
+        // A body that can ALWAYS match the empty string: k{n,m} = (k+){0,m} and k{n,} = (k+)*, where k+ is k without the
+        // empty match — the same positions and edges with the nullable flag cleared.  Copies then link to their neighbours
+        // only, instead of every copy to every later one ((a?){n} would have n^2 / 2 edges).
+        const bool strip = nullable_tt(k) == HG_TT_ALL;
+        auto copy = [&]() {
+          Frag f = build(k);
+          if (strip) f.nullable = 0;
+          return f;
+        };
+        const int mn = strip ? 0 : n.min;
         Frag acc;
         acc.nullable = HG_TT_ALL;
-        for (int i = 0; i < n.min; i++) acc = cat(acc, build(k));
+        for (int i = 0; i < mn; i++) acc = cat(std::move(acc), copy());
         if (n.max < 0) {
-          Frag loop = build(k);
+          Frag loop = copy();
           link(loop.last, loop.first);
           loop.nullable = HG_TT_ALL;
-          acc = cat(acc, loop);
-        } else {
-          // k{0,m} as (k(k(k)?)?)? : linear number of edges
-          Frag tail;
-          tail.nullable = HG_TT_ALL;
-          for (int i = n.min; i < n.max; i++) {
-            tail = cat(build(k), tail);
-            tail.nullable = HG_TT_ALL;
+          acc = cat(std::move(acc), std::move(loop));
+        } else if (n.max > mn) {
+          // k{0,m} as (((k)?k)?k)? : a string of j copies uses the LAST j of them, so the optional part is entered at any
+          // copy (the entering node's range of targets) and left from the last one only; copies are laid out in the order
+          // they are matched, which makes the edge from one copy to the next a node -> node + 1 edge wherever k is a chain.
+          Frag opt;
+          opt.nullable = HG_TT_ALL;
+          for (int i = mn; i < n.max; i++) {
+            opt = cat(std::move(opt), copy());
+            opt.nullable = HG_TT_ALL;
           }
-          acc = cat(acc, tail);
+          acc = cat(std::move(acc), std::move(opt));
         }
         return acc;
       }
@@ -696,34 +761,33 @@ class Glushkov {
   }
 
  private:
-  static void merge(std::vector<Cond> &dst, uint32_t pos, uint32_t tt) {
-    if (!tt) return;
-    for (auto &c : dst)
-      if (c.pos == pos) { c.tt |= tt; return; }
-    dst.push_back({pos, tt});
-  }
   void link(const std::vector<Cond> &from, const std::vector<Cond> &to) {
+    if (edges.size() + from.size() * to.size() > HG_HUGE_MAX_EDGES) throw CompileError("pattern too large");
     for (auto &l : from)
       for (auto &f : to) {
         uint32_t tt = l.tt & f.tt;
-        if (tt) edges[{l.pos, f.pos}] |= tt;
+        if (tt) edges.push_back({l.pos, f.pos, tt});
       }
   }
-  Frag cat(const Frag &a, const Frag &b) {
-    Frag r;
+  Frag cat(Frag a, Frag b) {
     link(a.last, b.first);
+    Frag r;
     r.nullable = a.nullable & b.nullable;
-    r.first = a.first;
-    for (auto &f : b.first) merge(r.first, f.pos, f.tt & a.nullable);
-    r.last = b.last;
-    for (auto &l : a.last) merge(r.last, l.pos, l.tt & b.nullable);
+    r.first = std::move(a.first);
+    if (a.nullable)
+      for (auto &f : b.first)
+        if (f.tt & a.nullable) r.first.push_back({f.pos, f.tt & a.nullable});
+    r.last = std::move(b.last);
+    if (b.nullable)
+      for (auto &l : a.last)
+        if (l.tt & b.nullable) r.last.push_back({l.pos, l.tt & b.nullable});
     return r;
   }
-  static Frag alt(const Frag &a, const Frag &b) {
-    Frag r = a;
+  static Frag alt(Frag a, Frag b) {
+    Frag r = std::move(a);
     r.nullable |= b.nullable;
-    for (auto &f : b.first) merge(r.first, f.pos, f.tt);
-    for (auto &l : b.last) merge(r.last, l.pos, l.tt);
+    r.first.insert(r.first.end(), b.first.begin(), b.first.end());
+    r.last.insert(r.last.end(), b.last.begin(), b.last.end());
     return r;
   }
 };
@@ -1349,31 +1413,38 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
       NodeP root = parser.parse();
       check_embedded_anchors(*root, false, false);
 
+      if (program_size(*root) > HG_HUGE_MAX_PROGRAM) throw CompileError("pattern too large");
       Glushkov g;
       Frag top = g.build(*root);
       if (top.nullable) throw CompileError("expression can match the empty string (HS_FLAG_ALLOWEMPTY is not supported)");
       if (g.pos_class.empty()) throw CompileError("expression matches nothing");
 
-      // nodes = distinct (position, entry condition)
-      std::map<std::pair<uint32_t, uint32_t>, uint32_t> node_id;
+      // one edge per (p, q): the ways of getting from p to q (through different assertions) merge into one condition
+      std::sort(g.edges.begin(), g.edges.end(), [](const Edge &x, const Edge &y) { return x.p != y.p ? x.p < y.p : x.q < y.q; });
+      {
+        size_t out_n = 0;
+        for (size_t i = 0; i < g.edges.size(); i++) {
+          if (out_n && g.edges[out_n - 1].p == g.edges[i].p && g.edges[out_n - 1].q == g.edges[i].q) g.edges[out_n - 1].tt |= g.edges[i].tt;
+          else g.edges[out_n++] = g.edges[i];
+        }
+        g.edges.resize(out_n);
+      }
+      // nodes = distinct (position, entry condition), numbered in (position, condition) order: linear expressions get
+      // follow = next bit, and the nodes of one position are consecutive
       std::vector<std::pair<uint32_t, uint32_t>> nodes;
+      nodes.reserve(top.first.size() + g.edges.size());
+      for (auto &c : top.first) nodes.push_back({c.pos, c.tt});
+      for (auto &e : g.edges) nodes.push_back({e.q, e.tt});
+      std::sort(nodes.begin(), nodes.end());
+      nodes.erase(std::unique(nodes.begin(), nodes.end()), nodes.end());
+      if (nodes.size() > HG_HUGE_MAX_NODES) throw CompileError("pattern too large");
       auto intern = [&](uint32_t pos, uint32_t tt) {
-        auto key = std::make_pair(pos, tt);
-        auto it = node_id.find(key);
-        if (it != node_id.end()) return it->second;
-        uint32_t id = static_cast<uint32_t>(nodes.size());
-        node_id.emplace(key, id);
-        nodes.push_back(key);
-        return id;
+        return static_cast<uint32_t>(std::lower_bound(nodes.begin(), nodes.end(), std::make_pair(pos, tt)) - nodes.begin());
       };
-      // order nodes by position so that linear expressions get follow = next bit
-      std::vector<std::pair<uint32_t, uint32_t>> wanted;
-      for (auto &c : top.first) wanted.push_back({c.pos, c.tt});
-      for (auto &e : g.edges) wanted.push_back({e.first.second, e.second});
-      std::sort(wanted.begin(), wanted.end());
-      wanted.erase(std::unique(wanted.begin(), wanted.end()), wanted.end());
-      for (auto &w : wanted) intern(w.first, w.second);
-      if (nodes.size() > HG_MAX_NODES) throw CompileError("pattern too large");
+      const uint32_t npos = static_cast<uint32_t>(g.pos_class.size());
+      std::vector<uint32_t> node_lo(npos + 1, 0);  // nodes of position q: [node_lo[q], node_lo[q + 1])
+      for (auto &nd : nodes) node_lo[nd.first + 1]++;
+      for (uint32_t q = 0; q < npos; q++) node_lo[q + 1] += node_lo[q];
 
       // (an expression whose every entry condition is contradictory, e.g. \b\Bc, has no nodes: it keeps one all-zero state
       // word so that every routine sees well-formed tables and simply never matches)
@@ -1385,37 +1456,145 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
       p.nw = nw;
       p.single = (f & HG_FLAG_SINGLEMATCH) ? 1 : 0;
       auto alloc = [&](size_t words) {
+        if (db->pool.size() + words > 0xFFFF0000ull) throw CompileError("pattern set too large");
         uint32_t off = static_cast<uint32_t>(db->pool.size());
         db->pool.resize(db->pool.size() + words, 0);
         return off;
       };
-      p.reach_off = alloc(256 * nw);
-      p.follow_off = alloc(static_cast<size_t>(nn) * nw);
-      p.init_off = alloc(nw);
-      p.amask_off = alloc(16 * nw);
-      p.acc_off = alloc(20 * nw);
-      std::vector<uint32_t> last_tt(g.pos_class.size(), 0);
+      std::vector<uint32_t> last_tt(npos, 0);
       for (auto &l : top.last) last_tt[l.pos] |= l.tt;
       auto setbit = [&](uint32_t base, uint32_t node) { db->pool[base + node / 32] |= 1u << (node % 32); };
-      for (uint32_t v = 0; v < nn; v++) {
-        uint32_t pos = nodes[v].first, tt = nodes[v].second;
-        for (int b = 0; b < 256; b++)
-          if (g.pos_class[pos][b]) setbit(p.reach_off + b * nw, v);
-        for (uint32_t pc = 0; pc < 4; pc++) {
-          for (uint32_t cc = 0; cc < 4; cc++)
-            if (tt >> (pc * 5 + cc) & 1) setbit(p.amask_off + (pc * 4 + cc) * nw, v);
-          for (uint32_t nc = 0; nc < 5; nc++)
-            if (last_tt[pos] >> (pc * 5 + nc) & 1) setbit(p.acc_off + (pc * 5 + nc) * nw, v);
+      const bool huge = nw > HG_MAX_W;
+      if (!huge) {
+        p.reach_off = alloc(256 * nw);
+        p.follow_off = alloc(static_cast<size_t>(nn) * nw);
+        p.init_off = alloc(nw);
+        p.amask_off = alloc(16 * nw);
+        p.acc_off = alloc(20 * nw);
+        for (uint32_t v = 0; v < nn; v++) {
+          uint32_t pos = nodes[v].first, tt = nodes[v].second;
+          for (int b = 0; b < 256; b++)
+            if (g.pos_class[pos][b]) setbit(p.reach_off + b * nw, v);
+          for (uint32_t pc = 0; pc < 4; pc++) {
+            for (uint32_t cc = 0; cc < 4; cc++)
+              if (tt >> (pc * 5 + cc) & 1) setbit(p.amask_off + (pc * 4 + cc) * nw, v);
+            for (uint32_t nc = 0; nc < 5; nc++)
+              if (last_tt[pos] >> (pc * 5 + nc) & 1) setbit(p.acc_off + (pc * 5 + nc) * nw, v);
+          }
         }
+        for (auto &c : top.first) setbit(p.init_off, intern(c.pos, c.tt));
+        for (auto &e : g.edges) {
+          uint32_t to = intern(e.q, e.tt);
+          for (uint32_t v = node_lo[e.p]; v < node_lo[e.p + 1]; v++) setbit(p.follow_off + v * nw, to);
+        }
+      } else {
+        // ---- huge automaton: sparse tables (HgHugeHeader, hg_db.h)
+        db->nhuge++;
+        db->huge_max_nw = std::max(db->huge_max_nw, nw);
+        // byte classes: bytes that belong to the same position classes are one class
+        std::vector<ByteSet> distinct;
+        {
+          std::map<std::string, uint32_t> seen;
+          for (auto &cs : g.pos_class) {
+            std::string key = cs.to_string();
+            if (seen.emplace(key, 0).second) distinct.push_back(cs);
+          }
+        }
+        uint32_t cls_of[256], ncls = 0;
+        uint32_t rep[256];  // a representative byte of each class
+        {
+          std::map<std::vector<bool>, uint32_t> sig_cls;
+          for (int b = 0; b < 256; b++) {
+            std::vector<bool> sig(distinct.size());
+            for (size_t d = 0; d < distinct.size(); d++) sig[d] = distinct[d][b];
+            auto it = sig_cls.find(sig);
+            if (it == sig_cls.end()) {
+              rep[ncls] = static_cast<uint32_t>(b);
+              it = sig_cls.emplace(std::move(sig), ncls++).first;
+            }
+            cls_of[b] = it->second;
+          }
+        }
+        bool ctxfree = true;
+        for (uint32_t v = 0; v < nn; v++) ctxfree = ctxfree && nodes[v].second == HG_TT_ALL;
+        for (uint32_t q = 0; q < npos; q++) ctxfree = ctxfree && (last_tt[q] == 0 || last_tt[q] == HG_TT_ALL);
+        const uint32_t hdr_off = alloc(sizeof(HgHugeHeader) / 4);
+        const uint32_t cls_off = alloc(64);
+        for (int b = 0; b < 256; b++) db->pool[cls_off + b / 4] |= cls_of[b] << ((b & 3) * 8);
+        p.reach_off = alloc(static_cast<size_t>(ncls) * nw);
+        p.follow_off = hdr_off;
+        p.init_off = alloc(nw);
+        const uint32_t smask_off = alloc(nw), xsrc_off = alloc(nw), xrank_off = alloc(nw);
+        p.amask_off = ctxfree ? p.init_off : alloc(16 * static_cast<size_t>(nw));  // (never read when ctxfree)
+        p.acc_off = alloc((ctxfree ? 1 : 20) * static_cast<size_t>(nw));
+        for (uint32_t v = 0; v < nn; v++) {
+          const uint32_t pos = nodes[v].first, tt = nodes[v].second;
+          for (uint32_t c = 0; c < ncls; c++)
+            if (g.pos_class[pos][rep[c]]) setbit(p.reach_off + c * nw, v);
+          if (ctxfree) {
+            if (last_tt[pos]) setbit(p.acc_off, v);
+            continue;
+          }
+          for (uint32_t pc = 0; pc < 4; pc++) {
+            for (uint32_t cc = 0; cc < 4; cc++)
+              if (tt >> (pc * 5 + cc) & 1) setbit(p.amask_off + (pc * 4 + cc) * nw, v);
+            for (uint32_t nc = 0; nc < 5; nc++)
+              if (last_tt[pos] >> (pc * 5 + nc) & 1) setbit(p.acc_off + (pc * 5 + nc) * nw, v);
+          }
+        }
+        for (auto &c : top.first) setbit(p.init_off, intern(c.pos, c.tt));
+        uint32_t init_hi = 0;
+        for (uint32_t w = 0; w < nw; w++)
+          if (db->pool[p.init_off + w]) init_hi = w + 1;
+        // follow: per source node its sorted targets; node -> node + 1 is a bit of smask, the rest become ranges
+        std::vector<uint32_t> xlist{0}, xt;
+        std::vector<uint32_t> targets;
+        size_t ei = 0;
+        for (uint32_t q = 0; q < npos; q++) {
+          targets.clear();
+          for (; ei < g.edges.size() && g.edges[ei].p == q; ei++) targets.push_back(intern(g.edges[ei].q, g.edges[ei].tt));
+          if (targets.empty()) continue;
+          std::sort(targets.begin(), targets.end());
+          targets.erase(std::unique(targets.begin(), targets.end()), targets.end());
+          for (uint32_t v = node_lo[q]; v < node_lo[q + 1]; v++) {  // every node of the position has the position's targets
+            bool any = false;
+            for (size_t t = 0; t < targets.size();) {
+              if (targets[t] == v + 1) { setbit(smask_off, v); t++; continue; }
+              size_t u = t;
+              while (u + 1 < targets.size() && targets[u + 1] == targets[u] + 1 && targets[u + 1] != v + 1) u++;
+              xt.push_back(targets[t]);
+              xt.push_back(targets[u]);
+              any = true;
+              t = u + 1;
+            }
+            if (any) {
+              setbit(xsrc_off, v);
+              xlist.push_back(static_cast<uint32_t>(xt.size() / 2));
+            }
+          }
+        }
+        for (uint32_t w = 0, run = 0; w < nw; w++) {
+          db->pool[xrank_off + w] = run;
+          run += static_cast<uint32_t>(__builtin_popcount(db->pool[xsrc_off + w]));
+        }
+        const uint32_t xlist_off = alloc(xlist.size()), xt_off = alloc(std::max<size_t>(xt.size(), 2));
+        std::copy(xlist.begin(), xlist.end(), db->pool.begin() + xlist_off);
+        std::copy(xt.begin(), xt.end(), db->pool.begin() + xt_off);
+        HgHugeHeader h{};
+        h.cls_off = cls_off;
+        h.ncls = ncls;
+        h.smask_off = smask_off;
+        h.xsrc_off = xsrc_off;
+        h.xrank_off = xrank_off;
+        h.xlist_off = xlist_off;
+        h.xt_off = xt_off;
+        h.ctxfree = ctxfree ? 1u : 0u;
+        h.init_hi = init_hi;
+        h.nsources = static_cast<uint32_t>(xlist.size() - 1);
+        h.nranges = static_cast<uint32_t>(xt.size() / 2);
+        std::memcpy(&db->pool[hdr_off], &h, sizeof h);
       }
-      for (auto &c : top.first) setbit(p.init_off, intern(c.pos, c.tt));
-      std::vector<std::vector<uint32_t>> nodes_of(g.pos_class.size());
-      for (uint32_t v = 0; v < nn; v++) nodes_of[nodes[v].first].push_back(v);
-      for (auto &e : g.edges) {
-        uint32_t to = intern(e.first.second, e.second);
-        for (uint32_t v : nodes_of[e.first.first]) setbit(p.follow_off + v * nw, to);
-      }
-      db->max_nw = std::max(db->max_nw, nw);
+      if (!huge) db->max_nw = std::max(db->max_nw, nw);
       db->max_id = std::max(db->max_id, p.id);
       if (nw == 1) {  // context-free single-word automaton: the confirm kernel's fast path
         bool simple = true;
@@ -1497,11 +1676,14 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
     }
     // always-on patterns of at most two state words go first: the segment-parallel kernel takes those
     auto two_words = [&](uint32_t pi) { return db->patterns[pi].nw <= 2; };  // bounded or not: an unbounded pattern's lead-in is the start of its line
+    auto not_huge = [&](uint32_t pi) { return db->patterns[pi].nw <= HG_MAX_W; };  // huge automata go last: their own kernel
+    std::stable_partition(db->slow.begin(), db->slow.end(), not_huge);
     std::stable_partition(db->slow.begin(), db->slow.end(), two_words);
     db->nslow_fast = static_cast<uint32_t>(std::count_if(db->slow.begin(), db->slow.end(), two_words));
+    db->nslow_huge = static_cast<uint32_t>(db->slow.size() - std::count_if(db->slow.begin(), db->slow.end(), not_huge));
     build_slow_groups(*db);
     // factors (needs the final fold mask); windows and filter tables are built from them
-    uint32_t rank_in_mode[HG_CONFIRM_MODES] = {0, 0, 0, 0};
+    uint32_t rank_in_mode[HG_CONFIRM_MODES] = {};
     for (unsigned i = 0; i < n; i++) {
       if (db->patterns[i].tier != 0) continue;
       const uint32_t mode = hg_confirm_mode(db->patterns[i]), rank = rank_in_mode[mode]++;

@@ -33,9 +33,12 @@ struct HgDb {
   std::vector<HgSlowGroup> groups;   // always-on expressions packed into shared state words (hg_db.h); their members are the
   uint32_t nslow_grouped = 0;        // first nslow_grouped entries of `slow`, group by group
   uint32_t fold_mask = 0;            // 0x20202020 when any tier-0 pattern is case-insensitive
-  uint32_t max_nw = 1;
+  uint32_t max_nw = 1;               // state words of the largest automaton with dense tables (<= HG_MAX_W)
+  uint32_t nhuge = 0;                // expressions with sparse tables (more than HG_MAX_NODES nodes: hg_db.h HgHugeHeader)
+  uint32_t huge_max_nw = 0;          // ... and the state words of the largest of them (sizes the LDS of the huge routines)
+  uint32_t nslow_huge = 0;           // huge always-on expressions: the LAST nslow_huge entries of `slow`
   uint32_t max_id = 0;               // largest report id (sizes the sort key)
-  uint32_t n_confirm_mode[HG_CONFIRM_MODES] = {0, 0, 0, 0};  // tier-0 patterns by confirm routine (hg_confirm_mode)
+  uint32_t n_confirm_mode[HG_CONFIRM_MODES] = {};  // tier-0 patterns by confirm routine (hg_confirm_mode)
   std::vector<std::string> exprs;
   bool tuned = false;
 };

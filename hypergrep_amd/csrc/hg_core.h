@@ -57,6 +57,7 @@ struct HgDbView {
   uint32_t window_mask;  // 0xFFFFFFFF, or 0x00FFFFFF for 3-byte windows
   uint32_t nslow_fast;  // the first nslow_fast entries of `slow` have <= 2 state words: hg_always_on_fast_kernel takes them
   uint32_t nslow_grouped;  // ... and the first nslow_grouped of those run as members of `groups` (HgSlowGroup), not one by one
+  uint32_t nslow_huge;     // the LAST nslow_huge entries of `slow` are huge automata (hg_always_on_huge_kernel)
   uint32_t ngroups;
   const HgSlowGroup *groups;
 };
@@ -94,9 +95,11 @@ HG_HD uint32_t hg_ctz(uint32_t x) {
 //   0  literal-only SINGLEMATCH expression: the verified literal occurrence is the match (no automaton run)
 //   1  context-free single-word SINGLEMATCH automaton (follow table in LDS)
 //   2  SINGLEMATCH automaton with <= 2 state words, boundary conditions allowed
-//   3  everything else (scalar reference routine)
-constexpr uint32_t HG_CONFIRM_MODES = 4;
+//   3  everything else of at most HG_MAX_W state words (scalar reference routine)
+//   4  huge automata (sparse tables, wave-cooperative routine: hg_huge.hip)
+constexpr uint32_t HG_CONFIRM_MODES = 5;
 HG_HD uint32_t hg_confirm_mode(const HgPattern &p) {
+  if (p.nw > HG_MAX_W) return 4;
   if (p.single && p.literal_only) return 0;
   if (p.single && p.simple) return 1;
   if (p.single && p.nw <= 2) return 2;
@@ -191,6 +194,91 @@ HG_HD void hg_trim_piece(const uint8_t *text, uint64_t ps, uint64_t limit, uint6
   }
 }
 
+// ---- huge automata (nw > HG_MAX_W): sparse tables (HgHugeHeader, hg_db.h) -------------------------------------------------
+struct HgHugeView {
+  uint32_t nw, ncls, ctxfree, init_hi;
+  const uint32_t *cls;    // 64 words: the class of each byte value, one byte each
+  const uint32_t *reach;  // reach[ncls][nw]
+  const uint32_t *init, *smask, *xsrc, *xrank, *xlist, *xt;
+  const uint32_t *amask;  // amask[4][4][nw]   (unless ctxfree)
+  const uint32_t *acc;    // acc[4][5][nw], or acc[nw] when ctxfree
+};
+HG_HD HgHugeView hg_huge_view(const uint32_t *pool, const HgPattern &p) {
+  const HgHugeHeader *h = reinterpret_cast<const HgHugeHeader *>(pool + p.follow_off);
+  HgHugeView v;
+  v.nw = p.nw;
+  v.ncls = h->ncls;
+  v.ctxfree = h->ctxfree;
+  v.init_hi = h->init_hi;
+  v.cls = pool + h->cls_off;
+  v.reach = pool + p.reach_off;
+  v.init = pool + p.init_off;
+  v.smask = pool + h->smask_off;
+  v.xsrc = pool + h->xsrc_off;
+  v.xrank = pool + h->xrank_off;
+  v.xlist = pool + h->xlist_off;
+  v.xt = pool + h->xt_off;
+  v.amask = pool + p.amask_off;
+  v.acc = pool + p.acc_off;
+  return v;
+}
+HG_HD uint32_t hg_huge_class(const HgHugeView &v, uint32_t c) { return (v.cls[c >> 2] >> ((c & 3u) * 8u)) & 0xFFu; }
+// the accepting-node mask for (context of the previous byte, context of the next) and the entry mask for (previous, own byte)
+HG_HD const uint32_t *hg_huge_acc(const HgHugeView &v, uint32_t pc, uint32_t nc) { return v.ctxfree ? v.acc : v.acc + (pc * 5 + nc) * v.nw; }
+// bits [lo & 31, 31] and [0, hi & 31] of a word
+HG_HD uint32_t hg_bits_from(uint32_t lo) { return 0xFFFFFFFFu << (lo & 31u); }
+HG_HD uint32_t hg_bits_upto(uint32_t hi) { return 0xFFFFFFFFu >> (31u - (hi & 31u)); }
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+// HOST mirror of the wave-cooperative device routine (hg_huge.hip huge_run): the same tables, the same step, one word at a
+// time.  The tests replay it against the oracle (tests/native/hostsim.cpp); the product never runs it.
+template <typename Emit>
+inline void hg_huge_scan_slice(const uint32_t *pool, const HgPattern &p, const uint8_t *data, uint64_t len, uint64_t from, uint64_t upto, Emit &&emit) {
+  const HgHugeView v = hg_huge_view(pool, p);
+  const uint32_t nw = v.nw;
+  const bool single = p.single != 0;
+  uint32_t *S = new uint32_t[2 * static_cast<size_t>(nw)](), *T = S + nw;
+  uint32_t pc = from ? hg_prev_ctx(data[from - 1]) : HG_PC_START;
+  bool alive = false;
+  auto any_accept = [&](const uint32_t *a) {
+    uint32_t any = 0;
+    for (uint32_t w = 0; w < nw; w++) any |= S[w] & a[w];
+    return any != 0;
+  };
+  for (uint64_t i = from; i < len; i++) {
+    if (i >= upto && !alive) { delete[] S; return; }
+    const uint32_t c = data[i];
+    const uint32_t cc = c == '\n' ? (i + 1 == len ? HG_NC_NLFINAL : HG_NC_NL) : (hg_is_word(c) ? HG_NC_WORD : HG_NC_OTHER);
+    if (alive && any_accept(hg_huge_acc(v, pc, cc))) {
+      emit(static_cast<uint32_t>(i));
+      if (single) { delete[] S; return; }
+    }
+    for (uint32_t w = 0; w < nw; w++) T[w] = i < upto ? v.init[w] : 0u;
+    for (uint32_t w = 0; w < nw; w++) {
+      const uint32_t x = S[w] & v.smask[w];
+      T[w] |= x << 1;
+      if (w + 1 < nw) T[w + 1] |= x >> 31;
+    }
+    for (uint32_t w = 0; w < nw; w++)
+      for (uint32_t x = S[w] & v.xsrc[w]; x; x &= x - 1) {
+        const uint32_t b = hg_ctz(x), k = v.xrank[w] + hg_popc(v.xsrc[w] & ((1u << b) - 1u));
+        for (uint32_t r = v.xlist[k]; r < v.xlist[k + 1]; r++) {
+          const uint32_t lo = v.xt[2 * r], hi = v.xt[2 * r + 1];
+          for (uint32_t tw = lo >> 5; tw <= (hi >> 5); tw++)
+            T[tw] |= (tw == (lo >> 5) ? hg_bits_from(lo) : 0xFFFFFFFFu) & (tw == (hi >> 5) ? hg_bits_upto(hi) : 0xFFFFFFFFu);
+        }
+      }
+    const uint32_t *r = v.reach + hg_huge_class(v, c) * nw, *m = v.ctxfree ? nullptr : v.amask + (pc * 4 + cc) * nw;
+    uint32_t any = 0;
+    for (uint32_t w = 0; w < nw; w++) any |= S[w] = T[w] & r[w] & (m ? m[w] : 0xFFFFFFFFu);
+    alive = any != 0;
+    pc = hg_prev_ctx(c);
+  }
+  if (alive && any_accept(hg_huge_acc(v, pc, HG_NC_END))) emit(static_cast<uint32_t>(len));
+  delete[] S;
+}
+#endif
+
 // Run one pattern's automaton over data[0, len) (one trimmed piece).  emit(to) per distinct match end
 // offset in ascending order; returns after the first when `single`.
 template <typename Emit>
@@ -199,6 +287,12 @@ HG_HD void hg_nfa_scan(const uint32_t *pool, const HgPattern &p, const uint8_t *
   const uint32_t *reach = pool + p.reach_off, *follow = pool + p.follow_off, *init = pool + p.init_off;
   const uint32_t *amask = pool + p.amask_off, *acc = pool + p.acc_off;
   const bool single = p.single != 0;
+  if (nw > HG_MAX_W) {  // a huge automaton: the device runs these wave-cooperatively (hg_huge.hip), never through this routine
+#if !defined(__HIP_DEVICE_COMPILE__)
+    hg_huge_scan_slice(pool, p, data, len, 0, len, emit);
+#endif
+    return;
+  }
   uint32_t pc = HG_PC_START;
   if (nw == 1) {
     uint32_t S = 0;
@@ -257,6 +351,12 @@ HG_HD void hg_nfa_scan_slice(const uint32_t *pool, const HgPattern &p, const uin
   const uint32_t *reach = pool + p.reach_off, *follow = pool + p.follow_off, *init = pool + p.init_off;
   const uint32_t *amask = pool + p.amask_off, *acc = pool + p.acc_off;
   const bool single = p.single != 0;
+  if (nw > HG_MAX_W) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    hg_huge_scan_slice(pool, p, data, len, from, upto, emit);
+#endif
+    return;
+  }
   uint32_t pc = from ? hg_prev_ctx(data[from - 1]) : HG_PC_START;
   if (nw == 1) {
     uint32_t S = 0;
@@ -339,9 +439,10 @@ HG_HD void hg_confirm_window(const HgDbView &db, const uint8_t *text, uint64_t n
 
 // Confirm one candidate: locate the piece containing byte `pos`, trim it, run the pattern.
 // emit(line_no, to, a, len) per report.
-template <typename Emit>
+// claim(piece start) -> false: the piece is not run (the caller has seen this (expression, piece) before).
+template <typename Emit, typename Claim>
 HG_HD void hg_confirm(const HgDbView &db, const uint8_t *text, uint64_t nbytes, const HgTileSum *sums,
-                      const HgTileBase *bases, uint64_t bs1, uint64_t pos, uint32_t pattern, uint32_t rank, Emit &&emit) {
+                      const HgTileBase *bases, uint64_t bs1, uint64_t pos, uint32_t pattern, uint32_t rank, Emit &&emit, Claim &&claim) {
   uint64_t t = pos >> HG_TILE_SHIFT, tile_start = t << HG_TILE_SHIFT;
   uint64_t s;
   if (rank == 0) {
@@ -357,8 +458,14 @@ HG_HD void hg_confirm(const HgDbView &db, const uint8_t *text, uint64_t nbytes, 
   uint64_t a, z;
   hg_trim_piece(text, ps, limit, a, z);
   if (z <= a) return;
+  if (!claim(ps)) return;
   const HgPattern &p = db.patterns[pattern];
   hg_nfa_scan(db.pool, p, text + a, z - a, [&](uint32_t to) { emit(line_no, to, a, static_cast<uint32_t>(z - a)); });
+}
+template <typename Emit>
+HG_HD void hg_confirm(const HgDbView &db, const uint8_t *text, uint64_t nbytes, const HgTileSum *sums,
+                      const HgTileBase *bases, uint64_t bs1, uint64_t pos, uint32_t pattern, uint32_t rank, Emit &&emit) {
+  hg_confirm(db, text, nbytes, sums, bases, bs1, pos, pattern, rank, emit, [](uint64_t) { return true; });
 }
 
 // Always-on tier: process every piece of the line that starts at absolute offset `s` (which has `rank`

@@ -23,8 +23,14 @@ enum : uint32_t { HG_PC_START = 0, HG_PC_NL = 1, HG_PC_WORD = 2, HG_PC_OTHER = 3
 enum : uint32_t { HG_NC_NL = 0, HG_NC_NLFINAL = 1, HG_NC_WORD = 2, HG_NC_OTHER = 3, HG_NC_END = 4 };     // next byte
 constexpr uint32_t HG_TT_ALL = (1u << 20) - 1;
 
-constexpr uint32_t HG_MAX_NODES = 1024;  // per pattern (32 state words)
+constexpr uint32_t HG_MAX_NODES = 1024;  // per pattern with DENSE tables (32 state words): the lane-private routines' limit
 constexpr uint32_t HG_MAX_W = HG_MAX_NODES / 32;
+// Larger automata ("huge": unrolled bounded repeats such as foo.{0,3000}bar, [a-z]{2000}x, a{32767}) keep the same node
+// semantics with SPARSE tables (HgHugeHeader below) and run wave-cooperatively with the state words in LDS (hg_huge.hip).
+// Limits: the expression's Thompson program size (what the oracle and Hyperscan's graph limits bound) and the node count.
+constexpr uint32_t HG_HUGE_MAX_PROGRAM = 400000;   // Thompson instructions of the expression (oracle/orx.c ORX_MAX_INST restates the same bound)
+constexpr uint32_t HG_HUGE_MAX_NODES = 1u << 19;   // (position, entry condition) nodes: 16384 state words = 64 KiB of LDS per state copy
+constexpr uint32_t HG_HUGE_MAX_EDGES = 1u << 22;   // automaton edges the compiler will hold (quadratic constructions such as (a?b?c?...){n} stop here)
 constexpr uint32_t HG_MAX_PATTERNS = 1u << 24;  // pattern index and window offset share one word in the verified-occurrence records
 constexpr uint32_t HG_ALWAYS_ON_FAST_MAX_LEN = 64;  // always-on patterns up to this match length use a fixed lead-in, longer / unbounded ones their line's start
 constexpr uint32_t HG_FACTOR_MAX = 32;   // bytes of a required literal kept for the in-stream verify
@@ -60,13 +66,35 @@ constexpr uint32_t HG_FILTER_EMPTY = 0xFFFFFFFFu;
 
 // One compiled expression: a position (Glushkov) automaton whose nodes are (position, entry condition).
 // Tables live in one u32 pool; *_off are indices into it.
+// Tables of a huge automaton (nw > HG_MAX_W).  HgPattern::follow_off points at this header in the pool; reach_off / init_off
+// / amask_off / acc_off keep their meaning with these shapes: reach[ncls][nw] (indexed by the byte's CLASS, cls[] below),
+// init[nw], and — unless ctxfree — amask[4][4][nw], acc[4][5][nw]; a ctxfree automaton (no boundary conditions) has no
+// amask and ONE acc[nw].  The follow relation is sparse: node v -> v + 1 edges are one bit of smask ("shift" edges: with
+// nodes numbered in expression order an unrolled repeat is almost all of them), every other edge is an "exception": the
+// sources are the bits of xsrc, source number k (xrank[w] + bits of xsrc[w] below it) owns the target ranges
+// xt[2 r], xt[2 r + 1] (first and last node, inclusive) for r in [xlist[k], xlist[k + 1]).
+struct HgHugeHeader {
+  uint32_t cls_off;    // pool: 64 words = 256 bytes, the class of each byte value
+  uint32_t ncls;
+  uint32_t smask_off;  // pool: smask[nw]
+  uint32_t xsrc_off;   // pool: xsrc[nw]
+  uint32_t xrank_off;  // pool: xrank[nw]
+  uint32_t xlist_off;  // pool: xlist[sources + 1]
+  uint32_t xt_off;     // pool: xt[2 * ranges]
+  uint32_t ctxfree;    // 1: no boundary conditions anywhere
+  uint32_t init_hi;    // one past the last non-zero word of init[]
+  uint32_t nsources, nranges;
+  uint32_t reserved[5];
+};
+static_assert(sizeof(HgHugeHeader) == 64, "HgHugeHeader layout");
+
 struct HgPattern {
   uint32_t id;          // report id given by the caller
   uint32_t flags;       // HS_FLAG_* bits
   uint32_t nnodes;      // automaton nodes
-  uint32_t nw;          // state words = ceil(nnodes / 32)
+  uint32_t nw;          // state words = ceil(nnodes / 32); more than HG_MAX_W: a huge automaton (HgHugeHeader)
   uint32_t reach_off;   // reach[256][nw]   nodes whose byte class contains c
-  uint32_t follow_off;  // follow[nnodes][nw]
+  uint32_t follow_off;  // follow[nnodes][nw]  (huge: the HgHugeHeader)
   uint32_t init_off;    // init[nw]         nodes enterable from the (always active) start state
   uint32_t amask_off;   // amask[4][4][nw]  nodes whose entry condition holds for (prev ctx, ctx of own byte)
   uint32_t acc_off;     // acc[4][5][nw]    nodes that accept for (ctx of own byte, next ctx)

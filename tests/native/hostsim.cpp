@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -138,6 +139,7 @@ static HgDbView view_of(HgDb *db) {
   v.nslow = db->slow.size();
   v.nslow_fast = db->nslow_fast;
   v.nslow_grouped = 0;  // (the host replay runs every always-on expression on its own)
+  v.nslow_huge = db->nslow_huge;
   v.ngroups = 0;
   v.groups = nullptr;
   v.fold_mask = db->fold_mask;
@@ -244,6 +246,7 @@ long hgsim_scan(void *h, const uint8_t *data, uint64_t nbytes, int buffer_size, 
   std::vector<HgHit> hits;
   std::vector<HgHitAux> aux;
   uint64_t verified = 0;
+  std::set<std::pair<uint64_t, uint32_t>> huge_done;  // (piece start, expression) pairs a huge automaton has run on
   for (auto &c : cands) {
     hg_verify_window(v, data, nbytes, c.pos, c.word, [&](uint32_t pattern, uint64_t fs, uint32_t) {
       verified++;
@@ -253,10 +256,18 @@ long hgsim_scan(void *h, const uint8_t *data, uint64_t nbytes, int buffer_size, 
       };
       // SINGLEMATCH automata of <= 2 state words are confirmed by window on the device (confirm modes 1 and 2): the same here
       const uint32_t mode = hg_confirm_mode(db->patterns[pattern]);
-      if ((mode == 1 || mode == 2) && !getenv("HGSIM_NO_WINDOW"))
+      if ((mode == 1 || mode == 2) && !getenv("HGSIM_NO_WINDOW")) {
         hg_confirm_window(v, data, nbytes, sums.data(), bases.data(), bs1, c.pos, fs, pattern, c.rank, emit);
-      else
+      } else if (mode == 4) {
+        // huge automata: ONE run per (expression, piece), whichever occurrence of the literal comes first — the device claims
+        // the pair in a hash table (hg_huge.hip); a literal that overlaps itself (a{32767}) gives a candidate per byte
+        bool fresh = false;
+        hg_confirm(v, data, nbytes, sums.data(), bases.data(), bs1, c.pos, pattern, c.rank, emit,
+                   [&](uint64_t ps) { return fresh = huge_done.insert({ps, pattern}).second; });
+        (void)fresh;
+      } else {
         hg_confirm(v, data, nbytes, sums.data(), bases.data(), bs1, c.pos, pattern, c.rank, emit);
+      }
     });
   }
   // ---- always-on tier: every line start

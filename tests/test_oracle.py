@@ -78,13 +78,15 @@ def test_reference_table_grep(case):
 REJECTED = [
     "(?<!foo)bar", "(?<=foo)bar", "foo(?=bar)", "foo(?!bar)", "(a)\\1", "(?>a+)b", "a*+", "a++", "(?(1)a|b)",
     "(?R)", "\\Gabc", "a\\Kb", "\\X", "\\R", "\\p{L}", "a*", "a?", "(a|b*)", "^", "$", "\\b", "(?:)", "a{3,2}",
-    "a{40000}", "(", ")", "a)", "[a", "[z-a]", "*a", "a**b" if False else "+a", "\\", "x{2,1}",
+    "a{40000}", "a{32768}", "(", ")", "a)", "[a", "[z-a]", "*a", "a**b" if False else "+a", "\\", "x{2,1}",
 ]
 ACCEPTED = [
     "foobar", "fo{2}bar", "fo+bar", "barfoo\\+", "a|b", "(a|b)c", "[a-z0-9_]{4,12}", "user=[a-z0-9_]{4,12} status=5[0-9]{2}",
     "^abc", "abc$", "\\bfoo\\b", "a.c", "(?i)abc", "(?i:a)b", "\\x41\\x{42}", "\\Qa.b\\E", "a{2}", "a{,3}", "{a", "a{x",
     "(?P<n>a)", "(?<n>a)", "(?#c)a", "[[:alpha:]]+", "[\\]a]", "[]a]", "[^]a]", "\\d+\\.\\d+", "a??b", "a*?b", "a+?",
     "\\101", "\\0", "[\\d-z]", "\\ca", "a\\z", "a\\Z", "\\Aa",
+    # beyond 1024 automaton positions (Hyperscan's bounded-repeat limit is 32767; more of them in tests/huge_cases.py)
+    "[a-z]{2000}x", ".{0,3000}foo", "foo.{0,3000}bar", "(abc|def){200}", "a{32767}",
 ]
 
 
