@@ -212,6 +212,8 @@ class HgScanner {
   uint32_t *d_fin_fill_ = nullptr, *d_fin_kept_ = nullptr, *d_fin_total_ = nullptr, *d_fin_big_ = nullptr;
   bool fin_fallback_ = false;
   uint64_t fin_expect_hits_ = 0;  // raw hits of the last pass: the next one picks its bucket count for ~24 records a bucket
+  void *d_huge_claim_ = nullptr;      // huge automata: (piece start, expression) pairs already run (hg_confirm_huge_kernel), 8-byte slots
+  uint64_t huge_claim_slots_ = 0;
   uint32_t *d_seg_count2_ = nullptr;  // second set for double buffering
   HgCand *d_cands2_ = nullptr;
 };

@@ -51,6 +51,12 @@ __global__ void hg_keep_kernel(const HgHit *hits, const HgHitAux *aux, const uin
 __global__ void hg_scatter_kernel(const HgHit *hits, const HgHitAux *aux, const uint32_t *perm, const uint8_t *keep, const uint32_t *pos, uint32_t n,
                                   HgHit *oh, HgHitAux *oa, uint32_t *count);
 
+// huge automata (hg_huge.hip)
+size_t hg_huge_lds_bytes(uint32_t nw_max);
+bool hg_launch_confirm_huge(const HgConfirmArgs &a, uint32_t grid, uint32_t nw_max, void *claim, uint32_t claim_mask, hipStream_t stream);
+bool hg_launch_always_on_huge(const HgConfirmArgs &a, uint32_t grid, uint32_t nw_max, uint32_t first, uint32_t last, hipStream_t stream);
+bool hg_launch_block_huge(const HgConfirmArgs &a, uint32_t grid, uint32_t nw_max, const uint32_t *pattern_flags, hipStream_t stream);
+
 namespace {
 constexpr int TS_BLOCK_TILES = 1024;  // must match hg_kernels.hip (256 threads x 4 tiles)
 constexpr int STREAM_WG_WAVES = HG_STREAM_WG_WAVES;
@@ -129,6 +135,7 @@ int HgScanner::create(std::shared_ptr<const HgDb> db, int device, HgScanner **ou
   s->view_.nslow = static_cast<uint32_t>(db->slow.size());
   s->view_.nslow_fast = db->nslow_fast;
   s->view_.nslow_grouped = db->nslow_grouped;
+  s->view_.nslow_huge = db->nslow_huge;
   s->view_.ngroups = static_cast<uint32_t>(db->groups.size());
   s->view_.groups = static_cast<const HgSlowGroup *>(s->d_groups_);
   s->view_.fold_mask = db->fold_mask;
@@ -160,7 +167,7 @@ HgScanner::~HgScanner() {
   (void)hipSetDevice(device_);
   void *ptrs[] = {d_patterns_, d_pool_, d_factors_, d_windows_, d_bucket_, d_filter_, d_ext_, d_slow_, d_sums_, d_bases_, d_block_base_,
                   d_agg_, d_cands_, d_hits_raw_, d_hits_out_, d_aux_raw_, d_aux_out_,
-                  d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, d_keep_, d_counters_, d_temp_, d_seg_count_, d_pflags_, d_deferred_, d_defer_count_, d_seg_count2_, d_cands2_, d_disc_, d_bucket2_, d_windows2_, d_groups_, d_acc_hits_, d_acc_aux_};
+                  d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, d_keep_, d_counters_, d_temp_, d_seg_count_, d_pflags_, d_deferred_, d_defer_count_, d_seg_count2_, d_cands2_, d_disc_, d_bucket2_, d_windows2_, d_groups_, d_acc_hits_, d_acc_aux_, d_huge_claim_};
   for (void *p : ptrs) hgmem::dev_free(p, "scanner");
   hgmem::host_free(h_counters_, "h_counters_");
   for (auto &ev : ev_)
@@ -193,6 +200,16 @@ int HgScanner::alloc_cands(uint64_t n) {
   uint32_t modes = 0;
   for (uint32_t m = 0; m < HG_CONFIRM_MODES; m++) modes += db_->n_confirm_mode[m] ? 1 : 0;
   if (fail(hgmem::dev_alloc(&d_deferred_, std::max<uint64_t>(modes, 1) * n * sizeof(HgDeferred), "d_deferred_"), "workspace alloc (deferred)")) return HG_ERR_HIP;
+  // huge tier-0 expressions: the (piece, expression) claim table of hg_confirm_huge_kernel, two slots per occurrence a pass can hold
+  hgmem::dev_free(d_huge_claim_, "d_huge_claim_");
+  d_huge_claim_ = nullptr;
+  huge_claim_slots_ = 0;
+  if (db_->n_confirm_mode[4]) {
+    uint64_t slots = 1u << 12;
+    while (slots < 2 * n) slots <<= 1;
+    if (fail(hgmem::dev_alloc(&d_huge_claim_, slots * 8, "d_huge_claim_"), "workspace alloc (claim table)")) return HG_ERR_HIP;
+    huge_claim_slots_ = slots;
+  }
   cand_cap_ = static_cast<uint32_t>(n);
   return HG_OK;
 }
@@ -488,9 +505,13 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       if (block_mode) {
         HG_TRY(hipMemsetAsync(d_pflags_, 0, db_->patterns.size() * 4, side), "memset pattern flags");
         if (has_anchored) hipLaunchKernelGGL(hg_block_mark_kernel, dim3(segs_c), dim3(256), 0, side, ca, d_pflags_);
-        always_blocks = static_cast<uint32_t>((db_->patterns.size() + 255) / 256);
+        always_blocks = std::max<uint32_t>(static_cast<uint32_t>((db_->patterns.size() + 255) / 256), std::min<uint32_t>(db_->nhuge, 1024u));
         ca.hit_seg_cap = hit_cap_ / always_blocks;
-        hipLaunchKernelGGL(hg_block_scan_kernel, dim3(always_blocks), dim3(256), 0, side, ca, d_pflags_);
+        hipLaunchKernelGGL(hg_block_scan_kernel, dim3(static_cast<uint32_t>((db_->patterns.size() + 255) / 256)), dim3(256), 0, side, ca, d_pflags_);
+        if (db_->nhuge && !hg_launch_block_huge(ca, std::min<uint32_t>(db_->nhuge, 1024u), db_->huge_max_nw, d_pflags_, side)) {
+          err_ = "the huge-automaton kernel cannot have its LDS";
+          return HG_ERR_HIP;
+        }
         HG_TRY(hipGetLastError(), "block-mode launch");
       } else {
         const uint64_t span = t1 - t0;
@@ -506,7 +527,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
         if (piped && c + 1 == nchunks) HG_TRY(hipEventRecord(ev_tile_done_, side), "event");  // (the early finalize starts behind the tile scan)
         if (has_anchored) {
           const uint32_t verify_blocks = segs_c * HG_CONFIRM_SPLIT;  // HG_CONFIRM_SPLIT blocks share candidate segment b
-          uint32_t fast_modes = 0, mode_mask = 0xF;
+          uint32_t fast_modes = 0, mode_mask = 0x1F;
           if (const char *env = std::getenv("HG_DEBUG_CONFIRM_MODES")) mode_mask = static_cast<uint32_t>(std::strtoul(env, nullptr, 0));  // profiling aid: results are incomplete
           for (uint32_t m = 0; m < 3; m++) fast_modes += (db_->n_confirm_mode[m] && ((mode_mask >> m) & 1u)) ? 1 : 0;
           // few, long-lived blocks per confirm routine (in units of 256 lanes per CU; 3 measured best next to the stream pass);
@@ -514,7 +535,9 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
           uint32_t per_cu = c + 1 == nchunks ? 6 : 3;
           if (const char *env = std::getenv("HG_CONFIRM_BLOCKS_PER_CU")) per_cu = static_cast<uint32_t>(std::max(1l, std::min(16l, std::strtol(env, nullptr, 10))));
           const uint32_t mode_blocks = std::max<uint32_t>(HG_DEFER_SHARDS, static_cast<uint32_t>(num_cus_) * per_cu * (256 / HG_CONFIRM_THREADS));  // per_cu counts 256 lanes
-          confirm_blocks = std::max(mode_blocks * std::max(fast_modes, 1u), verify_blocks);  // the largest grid that stages hits
+          // huge automata (confirm mode 4): one-wave workgroups, as many per CU as their LDS allows (8 at most)
+          const uint32_t huge_blocks = db_->n_confirm_mode[4] ? std::max<uint32_t>(HG_DEFER_SHARDS, static_cast<uint32_t>(num_cus_) * static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(8, (160u << 10) / std::max<size_t>(hg_huge_lds_bytes(db_->huge_max_nw), 1))))) : 0u;
+          confirm_blocks = std::max(std::max(mode_blocks * std::max(fast_modes, 1u), verify_blocks), huge_blocks);  // the largest grid that stages hits
           ca.hit_seg_cap = hit_cap_ / confirm_blocks;
           ca.deferred = d_deferred_;
           ca.defer_count = d_defer_count_;
@@ -528,12 +551,19 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
           hipLaunchKernelGGL(hg_verify_kernel, dim3(verify_blocks), dim3(256), 0, side, ca);
           if (fast_modes) hipLaunchKernelGGL(hg_confirm_fast_kernel, dim3(mode_blocks * fast_modes), dim3(HG_CONFIRM_THREADS), 0, side, ca, mode_blocks);
           if (db_->n_confirm_mode[3]) hipLaunchKernelGGL(hg_confirm_generic_kernel, dim3(mode_blocks), dim3(256), 0, side, ca);
+          if (huge_blocks && ((mode_mask >> 4) & 1u)) {
+            HG_TRY(hipMemsetAsync(d_huge_claim_, 0, huge_claim_slots_ * 8, side), "memset claim table");
+            if (!hg_launch_confirm_huge(ca, huge_blocks, db_->huge_max_nw, d_huge_claim_, static_cast<uint32_t>(huge_claim_slots_ - 1), side)) {
+              err_ = "the huge-automaton kernel cannot have its LDS";
+              return HG_ERR_HIP;
+            }
+          }
           HG_TRY(hipGetLastError(), "confirm launch");
         }
         if (!db_->slow.empty()) {
           always_blocks = static_cast<uint32_t>(std::min<uint64_t>((span + 3) / 4, static_cast<uint64_t>(num_cus_) * 8));
           ca.hit_seg_cap = hit_cap_ / always_blocks;
-          const uint32_t nfast = db_->nslow_fast, nall = static_cast<uint32_t>(db_->slow.size());
+          const uint32_t nfast = db_->nslow_fast, nhuge = db_->nslow_huge, nall = static_cast<uint32_t>(db_->slow.size()) - nhuge;  // [fast | scalar | huge]
           if (nfast) {
             // the match list lives in the (by now idle) verified-occurrence lists: cand_cap_ entries at least, a segment per block
             ca.deferred = d_deferred_;
@@ -543,6 +573,10 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
             hipLaunchKernelGGL(hg_always_on_finish_kernel, dim3(always_blocks), dim3(256), 0, side, ca);
           }
           if (nall > nfast) hipLaunchKernelGGL(hg_always_on_kernel, dim3(always_blocks), dim3(256), 0, side, ca, nfast, nall);
+          if (nhuge && !hg_launch_always_on_huge(ca, always_blocks, db_->huge_max_nw, nall, nall + nhuge, side)) {
+            err_ = "the huge-automaton kernel cannot have its LDS";
+            return HG_ERR_HIP;
+          }
           HG_TRY(hipGetLastError(), "hg_always_on_kernel launch");
         }
       }
@@ -725,7 +759,7 @@ uint32_t HgScanner::launch_block_small(const uint8_t *h_text, uint32_t nbytes, h
   // 32 expressions per workgroup while 64 segments hold the set (their tables then usually fit in LDS), else 256
   const uint32_t ppw = view_.npatterns <= 32u * 64u ? 32u : 256u;
   const uint32_t segs = (view_.npatterns + ppw - 1) / ppw;
-  if (nbytes == 0 || nbytes > HG_BLOCK_SMALL_MAX || segs == 0 || segs > 64) return 0;
+  if (nbytes == 0 || nbytes > HG_BLOCK_SMALL_MAX || segs == 0 || segs > 64 || db_->nhuge) return 0;  // (huge automata: the general path)
   if (hipSetDevice(device_) != hipSuccess) return 0;
   hipLaunchKernelGGL(hg_block_small_kernel, dim3(segs), dim3(256), 0, stream, view_, h_text, nbytes, h_out, static_cast<uint32_t>(HG_BLOCK_SMALL_SEG), h_counts,
                      d_counters_ + HG_ST_BLOCK_DONE, h_flag, seq, ppw);

@@ -4,6 +4,8 @@ caused it; the test then fails with the child's output instead of taking the who
 
     python tests/gpu_cases.py guarded        parity cases on guarded text buffers (any over-read = GPU fault)
     python tests/gpu_cases.py many-sets      >= 48 distinct pattern sets through hyperscan(), HYPERGREP_POOL from the env
+    python tests/gpu_cases.py huge           expressions beyond 1024 automaton positions (tests/huge_cases.py): buffer API on guarded
+                                             buffers, the file API, block mode (hs_scan), mixed with ordinary expressions
 
 Prints one JSON line; exit code 0 = every case matched the oracle.
 """
@@ -120,7 +122,85 @@ def run_many_sets() -> dict:
     return {"ok": True, "sets": nsets, **device.faceb_stats()}
 
 
+def run_huge() -> dict:
+    """tests/huge_cases.py on the GPU: the wave-cooperative routine (hg_huge.hip) against the oracle — tier 0 (confirm mode
+    4, one run per piece and expression), always-on, all-matches mode, small scan buffers, text ending at an unmapped page."""
+    import ctypes
+
+    import hypergrep_amd
+    from huge_cases import ACCEPTED_HUGE, REJECTED_HUGE, SCAN_CASES, case_text
+    from hypergrep_amd import device, utils
+
+    bad, n = [], 0
+    for pat in ACCEPTED_HUGE:
+        if hypergrep_amd.check_compatibility([pat]) != 0:
+            bad.append({"case": "accept", "pattern": pat})
+    for pat in REJECTED_HUGE:
+        if hypergrep_amd.check_compatibility([pat]) != 4:
+            bad.append({"case": "reject", "pattern": pat})
+    arena = device.GuardedArena(2 << 20)
+    for ci, (pats, flags, ids, kind) in enumerate(SCAN_CASES):
+        db = device.Database(pats, flags=flags, ids=ids)
+        sc = device.Scanner(db, 0)
+        for seed in ((1,) if kind == "a32767" else (1, 2)):
+            text = case_text(kind, seed)
+            for bs in ((262140,) if kind == "a32767" else (262140, 2500)):
+                want, nlines = oracle_hits(text, pats, flags, ids, buffer_size=bs)
+                stats = sc.scan(arena.place(text), len(text), buffer_size=bs)
+                got = sorted(sc.hits())
+                if got != want or stats.n_lines != nlines:
+                    bad.append({"case": f"buffer-{ci}-{seed}-{bs}", "patterns": pats, "got": len(got), "want": len(want), "lines": [stats.n_lines, nlines],
+                                "extra": sorted(set(got) - set(want))[:6], "missing": sorted(set(want) - set(got))[:6]})
+                n += 1
+    # a huge expression among ordinary ones of every confirm mode, shared ids; then through the file API (batches, line bytes)
+    mixed = ["foo.{0,3000}bar", "needle_in_haystack", "fo+bar[0-9]", "\\bq[a-z]{1100,1300}\\b", "^[a-z]+ [a-z0-9 =._-]+$", "[a-z]{2000}x", "thread"]
+    mflags = [14, 14, 14, 14, 14, 6, 14]
+    mids = [0, 1, 0, 2, 3, 4, 1]
+    text = case_text("dotfoo", 5) + b"\n" + case_text("context", 5) + b"needle_in_haystack foobar7\n" + case_text("az2000x", 5)
+    want, nlines = oracle_hits(text, mixed, mflags, mids)
+    db = device.Database(mixed, flags=mflags, ids=mids)
+    sc = device.Scanner(db, 0)
+    stats = sc.scan(arena.place(text), len(text))
+    if sorted(sc.hits()) != want or stats.n_lines != nlines:
+        bad.append({"case": "mixed-buffer", "got": stats.n_hits, "want": len(want)})
+    n += 1
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as tmp:
+        path = os.path.join(tmp, "huge.log")
+        with open(path, "wb") as f:
+            f.write(text)
+        for bs, count in ((262140, 16), (3000, 5)):
+            want_rc, want_rows, want_batches = oracle_py.scan_file(path, mixed, mflags, mids, buffer_size=bs, buffer_count=count)
+            rows, batches = [], []
+
+            def on_match(matches, k, rows=rows, batches=batches):
+                batches.append(k)
+                for j in range(k):
+                    rows.append((matches[j].line_number, matches[j].id, matches[j].line))
+
+            rc = hypergrep_amd.scan(path, mixed, on_match, flags=mflags, ids=mids, buffer_size=bs, buffer_count=count)
+            if (rc, rows, batches) != (want_rc, want_rows, want_batches):
+                bad.append({"case": f"file-{bs}", "rc": [rc, want_rc], "rows": [len(rows), len(want_rows)]})
+            n += 1
+    # block mode (Face A): hs_scan on whole blocks, newlines are ordinary bytes
+    product = utils._get_hyperscanner_lib()  # pylint: disable=protected-access
+    oracle = ctypes.CDLL(os.path.join(oracle_py.ORACLE_DIR, "_build", "libhs.so.5"))
+    bpats = ["foo.{0,3000}bar", "[a-z]{2000}x", "(abc|def){200}", "plain_literal_here", "a.c"]
+    bflags, bids = [14, 6, 14, 14, 6], [0, 1, 2, 3, 4]
+    rng = random.Random(5)
+    word = lambda k: "".join(rng.choice("abcdefghijklmnopqrstuvwxyz") for _ in range(k)).encode()  # noqa: E731
+    blocks = [b"foo" + word(2500) + b"bar plain_literal_here abc\n", b"fo" + word(100) + b"bar\n", word(2105) + b"x" + word(50) + b"x", b"abcdef" * 130 + b"!",
+              b"foo\n" + word(10) + b"\nbar", word(1999) + b"x", b"x" * 9000 + b"foo" + b"y" * 3001 + b"bar"]
+    import test_gpu_parity as tg  # (the libhs driver used by the Face A tests)
+
+    got_ev, want_ev = tg._hs_events(product, bpats, bflags, bids, blocks), tg._hs_events(oracle, bpats, bflags, bids, blocks)  # pylint: disable=protected-access
+    for k, (g, w) in enumerate(zip(got_ev, want_ev)):
+        if g != w:
+            bad.append({"case": f"block-{k}", "got": len(g), "want": len(w), "extra": sorted(set(g) - set(w))[:4], "missing": sorted(set(w) - set(g))[:4]})
+        n += 1
+    return {"ok": not bad, "cases": n, "block_events": sum(len(w) for w in want_ev), "failed": bad[:8]}
+
+
 if __name__ == "__main__":
-    res = {"guarded": run_guarded, "many-sets": run_many_sets}[sys.argv[1]]()
+    res = {"guarded": run_guarded, "many-sets": run_many_sets, "huge": run_huge}[sys.argv[1]]()
     print(json.dumps(res), flush=True)
     sys.exit(0 if res.get("ok") else 1)

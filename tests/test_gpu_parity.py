@@ -946,6 +946,15 @@ def test_no_kernel_reads_past_the_text(torch_cuda):
     assert res["ok"] and res["cases"] >= 70, res
 
 
+def test_huge_patterns_match_oracle(torch_cuda):
+    """Expressions of more than 1024 automaton positions ([a-z]{2000}x, .{0,3000}foo, foo.{0,3000}bar,
+    (abc|def){200}, a{32767} gave rc 4): accept / reject as the oracle, and the wave-cooperative routine (hg_huge.hip)
+    against the oracle on texts with hits, near misses and lines longer than the repeat — buffer API on guarded buffers,
+    file API, block mode.  In a child process: new kernels, and a violation would be a GPU memory fault."""
+    res = _run_gpu_cases("huge", timeout=900)
+    assert res["ok"] and res["cases"] >= 30 and res["block_events"] >= 5, res
+
+
 def test_many_pattern_sets_through_the_file_api(torch_cuda):
     """48 distinct pattern sets through hyperscan() in ONE process, once with room for every context to stay alive (the
     state round 1's fault needed) and once with a pool of 4, which makes contexts change their pattern set (scanner
