@@ -1311,11 +1311,19 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
 // Packs single-word always-on expressions into shared state words (HgSlowGroup): first fit by node count, the expressions
 // with boundary conditions first (their bins run the routine with conditions, and whatever context-free expression still
 // fits rides along), then the context-free ones (bins of their own once the others are full).
-void build_slow_groups(HgDb &db) {
+// A/B knobs of the compiler (older code paths, for experiments and one test), read from the environment once per compile.
+struct CompileKnobs {
+  bool no_slow_groups = std::getenv("HG_NO_SLOW_GROUPS") != nullptr;
+  bool no_ctx_groups = std::getenv("HG_NO_CTX_GROUPS") != nullptr;
+  bool no_confirm_window = std::getenv("HG_NO_CONFIRM_WINDOW") != nullptr;
+  bool no_byte_windows = std::getenv("HG_NO_BYTE_WINDOWS") != nullptr;
+};
+
+void build_slow_groups(HgDb &db, const CompileKnobs &knobs) {
   db.groups.clear();
   db.nslow_grouped = 0;
-  if (std::getenv("HG_NO_SLOW_GROUPS")) return;
-  const bool mixed = !std::getenv("HG_NO_CTX_GROUPS");
+  if (knobs.no_slow_groups) return;
+  const bool mixed = !knobs.no_ctx_groups;
   struct Bin { std::vector<uint32_t> members; uint32_t nodes = 0; bool ctx = false; };
   std::vector<Bin> bins;
   for (int pass = 0; pass < 2; pass++) {  // 0: expressions with conditions, 1: context-free ones
@@ -1398,6 +1406,7 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
     if (err) *err = "too many expressions (limit 16777216)";
     return -4;
   }
+  const CompileKnobs knobs;
   auto db = std::make_unique<HgDb>();
   struct Pending { std::vector<Lit> lits; bool literal_only = false; };
   std::vector<Pending> covers(n);
@@ -1618,7 +1627,7 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
         }
       dedupe(cover);
       covers[cur].lits = cover;
-      p.lit_lead = (info.has_cover && lead >= 0 && !std::getenv("HG_NO_CONFIRM_WINDOW")) ? static_cast<uint32_t>(lead) : 0xFFFFFFFFu;
+      p.lit_lead = (info.has_cover && lead >= 0 && !knobs.no_confirm_window) ? static_cast<uint32_t>(lead) : 0xFFFFFFFFu;
       // literal-only: the expression's language is exactly one literal that fits the factor record, has no NUL
       // or inner newline, and no assertions -> a verified factor occurrence is a match
       if (info.exact && info.set.size() == 1 && cover.size() == 1 && info.set[0].bytes.size() <= HG_FACTOR_MAX &&
@@ -1681,7 +1690,7 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
     std::stable_partition(db->slow.begin(), db->slow.end(), two_words);
     db->nslow_fast = static_cast<uint32_t>(std::count_if(db->slow.begin(), db->slow.end(), two_words));
     db->nslow_huge = static_cast<uint32_t>(db->slow.size() - std::count_if(db->slow.begin(), db->slow.end(), not_huge));
-    build_slow_groups(*db);
+    build_slow_groups(*db, knobs);
     // factors (needs the final fold mask); windows and filter tables are built from them
     uint32_t rank_in_mode[HG_CONFIRM_MODES] = {};
     for (unsigned i = 0; i < n; i++) {
@@ -1708,7 +1717,7 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
     if (m >= HG_DENSE_MIN_FACTOR && m < HG_FAST_MIN_FACTOR) shortest = std::min(shortest, m);
   }
   int rc = -5;
-  if (shortest != SIZE_MAX && !std::getenv("HG_NO_BYTE_WINDOWS")) {
+  if (shortest != SIZE_MAX && !knobs.no_byte_windows) {
     // every literal of the set has at least 5 bytes: a window on both residues mod 2 fits, half the probes
     size_t set_shortest = SIZE_MAX;
     for (unsigned i = 0; i < n; i++)

@@ -27,16 +27,19 @@ struct HgDeferred {
   uint32_t rank;      // newlines between the tile start and pos
 };
 // The scanner's small device state is ONE block of words (reset by one launch, read back by one copy):
-//   [0, 8) counters, [8, 24) tile cursors, [24, 28) finalize totals {kept, raw, large buckets, -}, [28, 30) {count, overflow flag}
-//   of the finalize, [32, 36) tile-scan state (HgTileBase)
+//   [0, 8) counters, [24, 28) finalize totals {kept, raw, large buckets, -}, [28, 30) {count, overflow flag}
+//   of the finalize, [32, 36) tile-scan state (HgTileBase), [64, 128) tile cursors: one per pipeline chunk (a cursor of its own
+//   for each of the 64 chunks a pass may have, all zeroed by hg_reset_kernel: no chunk ever waits for, or races with, the
+//   reset of a cursor an earlier chunk has used)
 enum { HG_ST_FIN_TOTAL = 24, HG_ST_SELECTED = 28, HG_ST_FINAL = 32, HG_ST_WORDS = 36, HG_ST_ZERO_WORDS = 32,
        HG_ST_BLOCK_DONE = 40 };  // (outside the words a pass resets: workgroups of hg_block_small_kernel that have finished)
 enum { HG_CNT_CANDS = 0, HG_CNT_HITS = 1, HG_CNT_CAND_NEED = 2, HG_CNT_HIT_NEED = 3, HG_CNT_DEFER_NEED = 4,
        HG_CNT_HITS_WRAPPED = 5,  // the 32-bit hit counter went round (direct appends): the buffer is scanned in segments instead
        HG_CNT_JOIN_TILES = 6,  // tiles taken by the joiner launches of the pass (hg_stream_join_kernel)
        HG_CNT_WORDS = 8,
-       HG_CNT_CURSOR0 = 8,      // one tile cursor per pipeline chunk follows the counters proper
-       HG_CNT_ALL_WORDS = 8 + 16 };
+       HG_CNT_CURSOR0 = 64,     // one tile cursor per pipeline chunk (HgScanner::kMaxChunks = 64 of them)
+       HG_CNT_CURSORS = 64,
+       HG_ST_ALLOC_WORDS = 128 };
 constexpr uint32_t HG_STREAM_GRAB = 2 * HG_STREAM_WG_WAVES_DEFAULT;  // tiles per draw of a stream workgroup: two per wave
 
 // Bucketed finalize (hg_fin_*): buckets of the final ordering and the largest bucket one wave sorts in LDS.
@@ -125,6 +128,26 @@ struct HgScanOutput {
   uint64_t joiner_tiles;     // tiles (of 16 KiB) the joiner launches took: bytes the hg_stream_kernel launches did NOT stream
 };
 
+// Test / experiment knobs of the engine, read from the environment ONCE, when a scanner is created (never during a scan:
+// getenv is not safe against a concurrent setenv, and a scan must not change behaviour half-way).  None is needed in normal
+// use.  The limit-lowering ones exist so that tests reach segmented scans / chunk halving on small texts.
+struct HgEngineKnobs {
+  uint64_t fin_target = 48;        // HG_FIN_TARGET: reports per finalize bucket
+  bool no_bucket_finalize = false; // HG_NO_BUCKET_FINALIZE
+  uint64_t chunk_tiles = 0;        // HG_CHUNK_TILES: pipeline chunk size (0: default)
+  uint32_t max_chunks = 0;         // HG_MAX_CHUNKS (0: default)
+  std::string chunk_weights;       // HG_CHUNK_WEIGHTS: relative chunk sizes
+  long stream_wgs_per_cu = 0;      // HG_STREAM_WGS_PER_CU (0: default)
+  long joiner = -1;                // HG_JOINER (-1: default)
+  bool no_early_finalize = false;  // HG_NO_EARLY_FINALIZE
+  uint32_t confirm_mode_mask = 0x1F;  // HG_DEBUG_CONFIRM_MODES (profiling builds only: results are incomplete)
+  long confirm_blocks_per_cu = 0;  // HG_CONFIRM_BLOCKS_PER_CU (0: default)
+  uint64_t hit_limit = 0;          // HG_HIT_LIMIT (0: default 2^28)
+  uint64_t cand_limit = 0;         // HG_CAND_LIMIT (0: default 2^30)
+  bool verbose = false;            // HG_VERBOSE
+  static HgEngineKnobs from_env();
+};
+
 class HgScanner {
  public:
   // The scanner shares ownership of the (immutable) database: launch parameters are read from it on every scan.
@@ -162,6 +185,7 @@ class HgScanner {
                bool *overflow);
   bool fail(hipError_t e, const char *what);
 
+  HgEngineKnobs knobs_;
   int device_ = 0;
   int num_cus_ = 256;
   int stream_wgs_per_cu_ = 0;

@@ -76,6 +76,30 @@ uint32_t bits_for(uint64_t v) {
 }
 }  // namespace
 
+HgEngineKnobs HgEngineKnobs::from_env() {
+  HgEngineKnobs k;
+  auto num = [](const char *name, uint64_t dflt) -> uint64_t {
+    const char *env = std::getenv(name);
+    return env ? std::strtoull(env, nullptr, 10) : dflt;
+  };
+  k.fin_target = std::max<uint64_t>(4, num("HG_FIN_TARGET", 48));
+  k.no_bucket_finalize = std::getenv("HG_NO_BUCKET_FINALIZE") != nullptr;
+  k.chunk_tiles = num("HG_CHUNK_TILES", 0);
+  k.max_chunks = static_cast<uint32_t>(std::min<uint64_t>(num("HG_MAX_CHUNKS", 0), 1u << 20));
+  if (const char *env = std::getenv("HG_CHUNK_WEIGHTS")) k.chunk_weights = env;
+  k.stream_wgs_per_cu = static_cast<long>(num("HG_STREAM_WGS_PER_CU", 0));
+  if (const char *env = std::getenv("HG_JOINER")) k.joiner = std::max(0l, std::min(2l, std::strtol(env, nullptr, 10)));
+  k.no_early_finalize = std::getenv("HG_NO_EARLY_FINALIZE") != nullptr;
+#ifdef HG_PROFILE_CONFIRM
+  if (const char *env = std::getenv("HG_DEBUG_CONFIRM_MODES")) k.confirm_mode_mask = static_cast<uint32_t>(std::strtoul(env, nullptr, 0));
+#endif
+  k.confirm_blocks_per_cu = static_cast<long>(std::min<uint64_t>(num("HG_CONFIRM_BLOCKS_PER_CU", 0), 16));
+  k.hit_limit = num("HG_HIT_LIMIT", 0);
+  k.cand_limit = num("HG_CAND_LIMIT", 0);
+  k.verbose = std::getenv("HG_VERBOSE") != nullptr;
+  return k;
+}
+
 bool HgScanner::fail(hipError_t e, const char *what) {
   if (e == hipSuccess) return false;
   err_ = std::string(what) + ": " + hipGetErrorString(e);
@@ -101,6 +125,7 @@ int HgScanner::create(std::shared_ptr<const HgDb> db, int device, HgScanner **ou
   std::unique_ptr<HgScanner> s(new HgScanner());
   s->device_ = device;
   s->db_ = db;
+  s->knobs_ = HgEngineKnobs::from_env();
 #define HG_TRY(call, what)                         \
   if (s->fail((call), what)) {                     \
     if (err) *err = s->err_;                       \
@@ -140,8 +165,9 @@ int HgScanner::create(std::shared_ptr<const HgDb> db, int device, HgScanner **ou
   s->view_.groups = static_cast<const HgSlowGroup *>(s->d_groups_);
   s->view_.fold_mask = db->fold_mask;
   s->view_.window_mask = db->window_mask;
-  HG_TRY(hgmem::dev_alloc(&s->d_counters_, 64 * 4, "d_state_"), "alloc state");  // the state block (hg_engine.h, HG_ST_*)
-  HG_TRY(hipMemset(s->d_counters_, 0, 64 * 4), "clear state");
+  static_assert(HG_CNT_CURSORS == kMaxChunks, "one tile cursor per pipeline chunk");
+  HG_TRY(hgmem::dev_alloc(&s->d_counters_, HG_ST_ALLOC_WORDS * 4, "d_state_"), "alloc state");  // the state block (hg_engine.h, HG_ST_*)
+  HG_TRY(hipMemset(s->d_counters_, 0, HG_ST_ALLOC_WORDS * 4), "clear state");
   s->d_fin_total_ = s->d_counters_ + HG_ST_FIN_TOTAL;
   s->d_selected_ = s->d_counters_ + HG_ST_SELECTED;
   s->d_final_ = reinterpret_cast<HgTileBase *>(s->d_counters_ + HG_ST_FINAL);
@@ -153,9 +179,8 @@ int HgScanner::create(std::shared_ptr<const HgDb> db, int device, HgScanner **ou
   HG_TRY(hipEventCreateWithFlags(&s->ev_fin_early_, hipEventDisableTiming), "hipEventCreate");
   HG_TRY(hipEventCreateWithFlags(&s->ev_tile_done_, hipEventDisableTiming), "hipEventCreate");
 
-  HG_TRY(hgmem::dev_alloc(&s->d_fin_fill_, HG_FIN_MAX_BUCKETS * 4, "d_fin_fill_"), "alloc finalize buckets");
-  HG_TRY(hgmem::dev_alloc(&s->d_fin_kept_, HG_FIN_MAX_BUCKETS * 4, "d_fin_kept_"), "alloc finalize buckets");
-  HG_TRY(hgmem::dev_alloc(&s->d_fin_big_, 2 * HG_FIN_MAX_BUCKETS * 4, "d_fin_big_"), "alloc finalize buckets");  // (two work lists)
+  // (the bucket arrays of the finalize — 16 MiB — are allocated by the first pass that orders hits in buckets: a scratch that only
+  // ever sees short hs_scan blocks never needs them)
   // (the per-chunk events of the two-stream pipeline are created by the first scan that is large enough to use it: a
   // process that keeps dozens of scanners for small files would otherwise hold thousands of events for nothing)
 #undef HG_TRY
@@ -285,8 +310,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   if (own_len) {
     const uint64_t expect = std::max<uint64_t>(fin_expect_hits_, own_len >> 13);
     uint64_t want_nb = 1;
-    uint64_t per_bucket = 48;
-    if (const char *env = std::getenv("HG_FIN_TARGET")) per_bucket = std::max<uint64_t>(4, std::strtoull(env, nullptr, 10));
+    const uint64_t per_bucket = knobs_.fin_target;
     while (want_nb * per_bucket < expect && want_nb < HG_FIN_MAX_BUCKETS) want_nb <<= 1;
     while (((own_len - 1) >> fin_shift) >= want_nb) fin_shift++;
     fin_nb = static_cast<uint32_t>((own_len - 1) >> fin_shift) + 1;
@@ -294,8 +318,13 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   const uint32_t fin_cap = hit_cap_ / fin_nb;
   // (sort key of a bucket: line start inside the bucket | id | to | single; the raw records carry that start in the top
   // 24 bits of the line number, so line numbers must stay below 2^40)
-  const bool bucketed = ntiles && fin_cap && fin_shift <= 64 - HG_HIT_REL_SHIFT && fin_shift + id_bits + to_bits + 1 <= 64 &&
-                        bits_for(line_base + nbytes + 1) <= HG_HIT_REL_SHIFT && !fin_fallback_ && !std::getenv("HG_NO_BUCKET_FINALIZE");
+  if (ntiles && !d_fin_fill_ && !fin_fallback_) {
+    HG_TRY(hgmem::dev_alloc(&d_fin_fill_, HG_FIN_MAX_BUCKETS * 4, "d_fin_fill_"), "alloc finalize buckets");
+    HG_TRY(hgmem::dev_alloc(&d_fin_kept_, HG_FIN_MAX_BUCKETS * 4, "d_fin_kept_"), "alloc finalize buckets");
+    HG_TRY(hgmem::dev_alloc(&d_fin_big_, 2 * HG_FIN_MAX_BUCKETS * 4, "d_fin_big_"), "alloc finalize buckets");  // (two work lists)
+  }
+  const bool bucketed = ntiles && d_fin_fill_ && fin_cap && fin_shift <= 64 - HG_HIT_REL_SHIFT && fin_shift + id_bits + to_bits + 1 <= 64 &&
+                        bits_for(line_base + nbytes + 1) <= HG_HIT_REL_SHIFT && !fin_fallback_ && !knobs_.no_bucket_finalize;
   uint32_t fin_done = 0;  // buckets finalized so far
   // one launch puts the device state in place (counters, cursors, finalize totals, tile-scan state, bucket fill levels, the
   // first chunk's verified-occurrence counts)
@@ -313,18 +342,18 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   constexpr uint64_t kChunkTiles = 8ull << (30 - HG_TILE_SHIFT);
   if (!block_mode && ntiles >= 2 * kChunkTiles) nchunks = static_cast<uint32_t>(std::min<uint64_t>(kMaxChunks, ntiles / kChunkTiles));
   uint64_t chunk_tiles = ((ntiles + nchunks - 1) / nchunks + TS_BLOCK_TILES - 1) / TS_BLOCK_TILES * TS_BLOCK_TILES;
-  if (const char *env = std::getenv("HG_CHUNK_TILES")) {  // tests: force the chunked pipeline on small buffers
-    uint64_t v = std::strtoull(env, nullptr, 10);
+  if (knobs_.chunk_tiles) {  // tests: force the chunked pipeline on small buffers
+    const uint64_t v = knobs_.chunk_tiles;
     if (!block_mode && v >= TS_BLOCK_TILES) chunk_tiles = std::max<uint64_t>(v / TS_BLOCK_TILES * TS_BLOCK_TILES, (ntiles + kMaxChunks - 1) / kMaxChunks / TS_BLOCK_TILES * TS_BLOCK_TILES + TS_BLOCK_TILES);
   }
   if (!block_mode && chunk_limit_tiles_ && chunk_tiles > chunk_limit_tiles_) chunk_tiles = chunk_limit_tiles_;  // (a chunk's candidates did not fit before)
   nchunks = ntiles ? static_cast<uint32_t>((ntiles + chunk_tiles - 1) / chunk_tiles) : 1;
   uint32_t max_chunks = static_cast<uint32_t>(kMaxChunks);
-  if (const char *env = std::getenv("HG_MAX_CHUNKS")) max_chunks = static_cast<uint32_t>(std::max(1l, std::min<long>(kMaxChunks, std::strtol(env, nullptr, 10))));  // (tests)
+  if (knobs_.max_chunks) max_chunks = std::max(1u, std::min<uint32_t>(kMaxChunks, knobs_.max_chunks));  // (tests)
   if (nchunks > max_chunks) return HG_SPLIT;  // (chunks that shrank for a dense text: fewer tiles per pass then)
   std::vector<uint64_t> cut(nchunks + 1);  // chunk c = tiles [cut[c], cut[c + 1])
   for (uint32_t c = 0; c <= nchunks; c++) cut[c] = std::min<uint64_t>(tile_lo + static_cast<uint64_t>(c) * chunk_tiles, tile_hi);
-  if (const char *env = std::getenv("HG_CHUNK_WEIGHTS")) {  // experiment: relative chunk sizes, e.g. "10,10,8,4"
+  if (const char *env = knobs_.chunk_weights.empty() ? nullptr : knobs_.chunk_weights.c_str()) {  // experiment: relative chunk sizes, e.g. "10,10,8,4"
     std::vector<double> w;
     for (const char *q = env; *q;) {
       char *e = nullptr;
@@ -357,8 +386,8 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   if (ntiles) {
     if (stream_wgs_per_cu_ == 0) stream_wgs_per_cu_ = hg_stream_blocks_per_cu(db_->filter_log2, db_->filter_wide, db_->dense);
     uint32_t per_cu = piped ? std::max(1, stream_wgs_per_cu_ - 1) : stream_wgs_per_cu_;
-    if (const char *env = std::getenv("HG_STREAM_WGS_PER_CU")) {  // tuning knob: resident stream workgroups per CU
-      const long v = std::strtol(env, nullptr, 10);
+    if (knobs_.stream_wgs_per_cu) {  // tuning knob: resident stream workgroups per CU
+      const long v = knobs_.stream_wgs_per_cu;
       if (v >= 1 && v <= stream_wgs_per_cu_) per_cu = static_cast<uint32_t>(v);
     }
     auto grid_for = [&](uint32_t wgs_per_cu) {
@@ -367,7 +396,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
     };
     const uint32_t wgs_shared = grid_for(per_cu);  // next to the side passes of the previous chunk
     // the first chunk streams alone: every workgroup slot (unless the grid was fixed by hand)
-    const uint32_t wgs_alone = std::getenv("HG_STREAM_WGS_PER_CU") ? wgs_shared : grid_for(static_cast<uint32_t>(stream_wgs_per_cu_));
+    const uint32_t wgs_alone = knobs_.stream_wgs_per_cu ? wgs_shared : grid_for(static_cast<uint32_t>(stream_wgs_per_cu_));
     // Joiners: the side passes of chunk c - 1 take about half as long as the stream pass of chunk c; behind them, on the side
     // stream, a second launch of the stream kernel (one more workgroup per CU, its own candidate segments) joins chunk c and
     // draws tiles from the same cursor until the chunk is used up.
@@ -377,7 +406,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
     // Not for texts so dense in candidates that the chunks had to shrink: their side passes are the slower half anyway, and
     // the joiner's segments would take workspace from the others.
     uint32_t joiner_wgs = (piped && stream_wgs_per_cu_ >= 3 && per_cu < static_cast<uint32_t>(stream_wgs_per_cu_) && chunk_limit_tiles_ == 0 && !side_bound_) ? static_cast<uint32_t>(num_cus_) : 0u;
-    if (const char *env = std::getenv("HG_JOINER")) joiner_wgs = piped ? static_cast<uint32_t>(std::max(0l, std::min(2l, std::strtol(env, nullptr, 10)))) * static_cast<uint32_t>(num_cus_) : 0u;
+    if (knobs_.joiner >= 0) joiner_wgs = piped ? static_cast<uint32_t>(knobs_.joiner) * static_cast<uint32_t>(num_cus_) : 0u;
     if (wgs_shared + joiner_wgs > max_segs_ || db_->filter_wide || db_->filter_log2 > 13) joiner_wgs = 0;  // (hg_launch_stream_join's instantiations)
     wgs = std::max(wgs_shared + joiner_wgs, wgs_alone);  // sizes the regrowth of the candidate segments
     hipStream_t side = piped ? side_stream_ : stream;
@@ -436,8 +465,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       sa.dense = db_->dense;
       sa.weights_c = db_->weights_c;
       // the chunk's workgroups draw runs of consecutive tiles from a cursor (hg_stream_kernel): two tiles per wave and draw
-      sa.cursor_slot = HG_CNT_CURSOR0 + c % 16;
-      if (c >= 16) HG_TRY(hipMemsetAsync(d_counters_ + sa.cursor_slot, 0, 4, stream), "memset cursor");  // (chunk c - 16 finished with it long ago)
+      sa.cursor_slot = HG_CNT_CURSOR0 + c;  // (zeroed by hg_reset_kernel with the rest of the state block)
       sa.ext = static_cast<const HgSlotInfo *>(d_ext_);
       sa.sums = d_sums_;
       sa.cands = cands;
@@ -445,7 +473,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       const uint32_t joiners_c = c >= 1 ? joiner_wgs : 0u;
       const uint32_t segs_c = wgs_c + joiners_c;  // candidate segments of the chunk: one per stream workgroup
       sa.cand_seg_cap = cand_cap_ / segs_c;
-      sa.alone = (c == 0 && wgs_c == wgs_alone && !std::getenv("HG_STREAM_WGS_PER_CU")) ? 1u : 0u;
+      sa.alone = (c == 0 && wgs_c == wgs_alone && !knobs_.stream_wgs_per_cu) ? 1u : 0u;
       sa.counters = d_counters_;
       HG_TRY(hipEventRecord(piped ? ev_k1_begin_[c] : ev_[1], stream), "event");
       if (!hg_launch_stream(sa, wgs_c, stream)) {
@@ -454,7 +482,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       }
       HG_TRY(hipGetLastError(), "hg_stream_kernel launch");
       HG_TRY(hipEventRecord(piped ? ev_k1_end_[c] : ev_[2], stream), "event");
-      if (piped && bucketed && joiners_c && c + 1 == nchunks && !std::getenv("HG_NO_EARLY_FINALIZE")) {
+      if (piped && bucketed && joiners_c && c + 1 == nchunks && !knobs_.no_early_finalize) {
         // The last chunk: the side stream is idle from the end of chunk c - 1's side passes to the end of this stream launch.
         // The buckets the earlier chunks have completed are finalized there, in front of the joiner (they used to be
         // finalized beside the last chunk's verify / confirm passes, competing with them for the chip: 430 us for what takes
@@ -527,13 +555,13 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
         if (piped && c + 1 == nchunks) HG_TRY(hipEventRecord(ev_tile_done_, side), "event");  // (the early finalize starts behind the tile scan)
         if (has_anchored) {
           const uint32_t verify_blocks = segs_c * HG_CONFIRM_SPLIT;  // HG_CONFIRM_SPLIT blocks share candidate segment b
-          uint32_t fast_modes = 0, mode_mask = 0x1F;
-          if (const char *env = std::getenv("HG_DEBUG_CONFIRM_MODES")) mode_mask = static_cast<uint32_t>(std::strtoul(env, nullptr, 0));  // profiling aid: results are incomplete
+          uint32_t fast_modes = 0;
+          const uint32_t mode_mask = knobs_.confirm_mode_mask;  // (all modes, except in profiling builds: HG_DEBUG_CONFIRM_MODES)
           for (uint32_t m = 0; m < 3; m++) fast_modes += (db_->n_confirm_mode[m] && ((mode_mask >> m) & 1u)) ? 1 : 0;
           // few, long-lived blocks per confirm routine (in units of 256 lanes per CU; 3 measured best next to the stream pass);
           // the last chunk's side passes have the chip to themselves
           uint32_t per_cu = c + 1 == nchunks ? 6 : 3;
-          if (const char *env = std::getenv("HG_CONFIRM_BLOCKS_PER_CU")) per_cu = static_cast<uint32_t>(std::max(1l, std::min(16l, std::strtol(env, nullptr, 10))));
+          if (knobs_.confirm_blocks_per_cu) per_cu = static_cast<uint32_t>(knobs_.confirm_blocks_per_cu);
           const uint32_t mode_blocks = std::max<uint32_t>(HG_DEFER_SHARDS, static_cast<uint32_t>(num_cus_) * per_cu * (256 / HG_CONFIRM_THREADS));  // per_cu counts 256 lanes
           // huge automata (confirm mode 4): one-wave workgroups, as many per CU as their LDS allows (8 at most)
           const uint32_t huge_blocks = db_->n_confirm_mode[4] ? std::max<uint32_t>(HG_DEFER_SHARDS, static_cast<uint32_t>(num_cus_) * static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(8, (160u << 10) / std::max<size_t>(hg_huge_lds_bytes(db_->huge_max_nw), 1))))) : 0u;
@@ -580,7 +608,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
           HG_TRY(hipGetLastError(), "hg_always_on_kernel launch");
         }
       }
-      if (piped && bucketed && c + 1 == nchunks && c >= 1 && !std::getenv("HG_NO_EARLY_FINALIZE")) {
+      if (piped && bucketed && c + 1 == nchunks && c >= 1 && !knobs_.no_early_finalize) {
         // The last stream launch is queued.  Behind it, on this stream, the buckets that the earlier chunks have completed
         // are finalized WHILE the side stream works through the last chunk's verify / confirm passes (both have the chip to
         // themselves by then); only the last chunk's buckets remain for after those.  (Finalizing a chunk's buckets beside
@@ -637,7 +665,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   // Hit records one pass may hold (2^28: 8 GiB each of raw and ordered records); a buffer with more is scanned in segments
   // whose ordered hits are put one after the other (scan_segments).
   uint64_t kHitLimit = 1ull << 28;
-  if (const char *env = std::getenv("HG_HIT_LIMIT")) kHitLimit = std::max<uint64_t>(1u << 10, std::strtoull(env, nullptr, 10));  // (tests)
+  if (knobs_.hit_limit) kHitLimit = std::max<uint64_t>(1u << 10, knobs_.hit_limit);  // (tests)
   if (!block_mode && (n_raw > kHitLimit || h_counters_[HG_CNT_HITS_WRAPPED])) return HG_SPLIT;
   if (cand_need || defer_need || hit_need || fin_overflow || (!bucketed && n_raw > hit_cap_)) {
     // a private segment, a bucket or the compact hit array was too small: grow and let the caller repeat the pass
@@ -651,7 +679,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       // The workspace holds ONE chunk's candidates (two buffer sets): when that would pass 2^30 records (16 GiB a set) the
       // chunks get smaller instead — a text that fits in HBM always scans, a very dense one in more, smaller chunks.
       uint64_t kCandLimit = 1ull << 30;
-      if (const char *env = std::getenv("HG_CAND_LIMIT")) kCandLimit = std::max<uint64_t>(1u << 16, std::strtoull(env, nullptr, 10));  // (tests)
+      if (knobs_.cand_limit) kCandLimit = std::max<uint64_t>(1u << 16, knobs_.cand_limit);  // (tests)
       if (want > kCandLimit) {
         const uint64_t cur = (std::min<uint64_t>(chunk_tiles, ntiles) + TS_BLOCK_TILES - 1) / TS_BLOCK_TILES * TS_BLOCK_TILES;
         if (block_mode || cur <= TS_BLOCK_TILES) {
@@ -804,7 +832,7 @@ int HgScanner::scan_impl(const void *d_text, uint64_t nbytes, int buffer_size, u
       err_ = "workspace kept overflowing";
       return HG_ERR_NOMEM;
     }
-    if (std::getenv("HG_VERBOSE")) std::fprintf(stderr, "hypergrep_amd: workspace grown (cands %u, hits %u), repeating the pass\n", cand_cap_, hit_cap_);
+    if (knobs_.verbose) std::fprintf(stderr, "hypergrep_amd: workspace grown (cands %u, hits %u), repeating the pass\n", cand_cap_, hit_cap_);
   }
   if (rc == HG_SPLIT) {
     // More reports (or pipeline chunks) than one pass may have: the buffer is scanned in 2, 4, 8 ... segments.

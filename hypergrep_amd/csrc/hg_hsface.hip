@@ -12,6 +12,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/hypergrep_amd.h"
@@ -35,6 +36,18 @@ struct hs_scratch {
   uint32_t *h_counts = nullptr;  // [0, 64) reports per segment, [64] completion flag
   uint32_t seq = 0;
 };
+
+namespace {
+inline void cpu_relax() {  // a polite spin-wait hint, whatever the host is
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  __asm__ __volatile__("yield");
+#else
+  std::this_thread::yield();
+#endif
+}
+}  // namespace
 
 extern "C" {
 
@@ -77,22 +90,27 @@ int hs_alloc_scratch(const hs_database_t *db, hs_scratch_t **scratch) {
   if (*scratch && (*scratch)->db == db->db) return HS_SUCCESS;
   if (*scratch) hs_free_scratch(*scratch);
   *scratch = nullptr;
-  auto s = std::make_unique<hs_scratch>();
-  s->db = db->db;
+  // (a half-built scratch is handed to hs_free_scratch on every failure path: scanner, stream and pinned buffers are released)
+  struct Guard {
+    hs_scratch_t *p;
+    ~Guard() { if (p) hs_free_scratch(p); }
+  } s{new hs_scratch()};
+  s.p->db = db->db;
   std::string err;
   int device = 0;
   if (const char *env = std::getenv("HYPERGREP_DEVICE")) device = std::atoi(env);
-  if (HgScanner::create(s->db, device, &s->sc, &err) != HG_OK) {
+  if (HgScanner::create(s.p->db, device, &s.p->sc, &err) != HG_OK) {
     std::fprintf(stderr, "hypergrep_amd: hs_alloc_scratch: %s\n", err.c_str());
     return HS_NOMEM;
   }
-  if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) return HS_NOMEM;
-  if (hgmem::host_alloc(&s->h_text, HG_BLOCK_SMALL_MAX + 16, "hs h_text") != hipSuccess ||
-      hgmem::host_alloc(&s->h_out, 64 * HG_BLOCK_SMALL_SEG * sizeof(HgHit), "hs h_out") != hipSuccess ||
-      hgmem::host_alloc(&s->h_counts, 80 * sizeof(uint32_t), "hs h_counts") != hipSuccess)
+  if (hipStreamCreateWithFlags(&s.p->stream, hipStreamNonBlocking) != hipSuccess) return HS_NOMEM;
+  if (hgmem::host_alloc(&s.p->h_text, HG_BLOCK_SMALL_MAX + 16, "hs h_text") != hipSuccess ||
+      hgmem::host_alloc(&s.p->h_out, 64 * HG_BLOCK_SMALL_SEG * sizeof(HgHit), "hs h_out") != hipSuccess ||
+      hgmem::host_alloc(&s.p->h_counts, 80 * sizeof(uint32_t), "hs h_counts") != hipSuccess)
     return HS_NOMEM;
-  s->h_counts[64] = 0;
-  *scratch = s.release();
+  s.p->h_counts[64] = 0;
+  *scratch = s.p;
+  s.p = nullptr;
   return HS_SUCCESS;
 }
 
@@ -128,7 +146,7 @@ int hs_scan(const hs_database_t *db, const char *data, unsigned int length, unsi
       // sleeps until an interrupt); after ~2 ms of polling fall back to the synchronisation, which also reports errors
       volatile uint32_t *flag = scratch->h_counts + 64;
       bool done = false;
-      for (uint32_t spin = 0; spin < 400000 && !(done = *flag == seq); spin++) __builtin_ia32_pause();
+      for (uint32_t spin = 0; spin < 400000 && !(done = *flag == seq); spin++) cpu_relax();
       if (!done && hipStreamSynchronize(scratch->stream) != hipSuccess) return HS_INVALID;
       std::atomic_thread_fence(std::memory_order_acquire);
       bool fits = true;

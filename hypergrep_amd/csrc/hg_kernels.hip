@@ -1016,12 +1016,9 @@ __global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
       }
     }
   }
-#ifdef HG_PROFILE_CONFIRM
-  const uint64_t pf_t1 = wall_clock64();
-#endif
   verify_stage_flush(a, s_stage);
 #ifdef HG_PROFILE_CONFIRM
-  if (lane == 0) a.tmp_hits[(6u << 20) + 65536u + blockIdx.x * 4u + wave] = HgHit{pf_t0, static_cast<uint32_t>(wall_clock64() - pf_t0), pf_rounds | (pf_pairs << 8) | (static_cast<uint32_t>(pf_t1 - pf_t0) > 0xFFFFu ? 0u : 0u)};
+  if (lane == 0) a.tmp_hits[(6u << 20) + 65536u + blockIdx.x * 4u + wave] = HgHit{pf_t0, static_cast<uint32_t>(wall_clock64() - pf_t0), pf_rounds | (pf_pairs << 8)};
 #endif
 }
 
@@ -1861,6 +1858,7 @@ __global__ void hg_reset_kernel(uint32_t *state, uint32_t state_words, HgTileBas
                                 uint32_t *defer_count, uint32_t ndefer) {
   const uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
   for (uint32_t i = i0; i < state_words; i += stride) state[i] = 0;
+  for (uint32_t i = i0; i < HG_CNT_CURSORS; i += stride) state[HG_CNT_CURSOR0 + i] = 0;  // every pipeline chunk's tile cursor
   for (uint32_t i = i0; i < nb; i += stride) fill[i] = 0;
   for (uint32_t i = i0; i < ndefer; i += stride) defer_count[i] = 0;
   if (i0 == 0) *final_state = HgTileBase{carry_start, first_piece};
