@@ -1002,7 +1002,8 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
   const uint32_t wbytes = db.window_bytes, wmask = db.window_mask;
   for (uint32_t fi = 0; fi < db.nreal_factors; fi++) {
     const HgFactor &fct = db.factors[fi];
-    Lit l{std::string(reinterpret_cast<const char *>(fct.lit), fct.len), std::string(reinterpret_cast<const char *>(fct.cmask), fct.len)};
+    Lit l{std::string(reinterpret_cast<const char *>(fct.lit), fct.len), std::string(fct.len, '\xFF')};
+    for (uint32_t b = 0; b < fct.len; b++) l.cmask[b] = static_cast<char>(hg_factor_cmask(fct, b));
     if (db.dense && fct.len < wbytes) {
       // a literal one byte short of a window: every value of the byte after it (the stream pass reads zeros past the text)
       std::vector<uint32_t> seen;
@@ -1125,6 +1126,40 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
     if (db.windows2.empty()) db.windows2.push_back(HgWindow{0, 0});
   }
 
+  // Direct window table (hg_db.h HgWinEntry): every distinct window value once, with its (literal, offset) when there is only one.
+  {
+    std::vector<std::pair<uint32_t, uint32_t>> vf;  // (value, factor_off)
+    for (auto &kw : keyed) vf.push_back({kw.second.value, kw.second.factor_off});
+    std::sort(vf.begin(), vf.end());
+    vf.erase(std::unique(vf.begin(), vf.end()), vf.end());
+    size_t distinct = 0;
+    for (size_t i = 0; i < vf.size(); i++) distinct += (i == 0 || vf[i].first != vf[i - 1].first) ? 1 : 0;
+    uint32_t nbuckets = 16;
+    while (static_cast<size_t>(nbuckets) * HG_WTAB_WAYS < 2 * distinct) nbuckets <<= 1;
+    db.wtab.assign(static_cast<size_t>(nbuckets) * HG_WTAB_WAYS, HgWinEntry{0, 0, 0, 0});
+    db.wtab_mask = nbuckets - 1;
+    bool all_single = true;
+    for (size_t i = 0; i < vf.size();) {
+      size_t j = i;
+      while (j < vf.size() && vf[j].first == vf[i].first) j++;
+      const HgWinEntry e{vf[i].first, vf[i].second, static_cast<uint32_t>(j - i), 0};
+      all_single = all_single && e.count == 1;
+      for (uint32_t b = hg_wtab_bucket(e.value, db.wtab_mask);; b = (b + 1u) & db.wtab_mask) {
+        bool placed_here = false;
+        for (uint32_t k = 0; k < HG_WTAB_WAYS && !placed_here; k++)
+          if (db.wtab[static_cast<size_t>(b) * HG_WTAB_WAYS + k].count == 0) {
+            db.wtab[static_cast<size_t>(b) * HG_WTAB_WAYS + k] = e;
+            placed_here = true;
+          }
+        if (placed_here) break;
+      }
+      i = j;
+    }
+    bool literal_set = db.nreal_factors > 0;
+    for (uint32_t m = 1; m < HG_CONFIRM_MODES; m++) literal_set = literal_set && db.n_confirm_mode[m] == 0;
+    db.literal_direct = (literal_set && all_single) ? 1u : 0u;
+  }
+
   // LDS filter over the distinct window values (single-probe slots below; two-slot cells in wide mode).
   std::vector<uint32_t> values;
   for (auto &kw : keyed) values.push_back(kw.second.value);
@@ -1213,8 +1248,8 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
         if (!fold) {  // case-insensitive letters cannot be compared exactly without folding: drop them
           for (int b = 0; b < 4; b++) {
             int jp = o - 4 + b, jn = o + static_cast<int>(wbytes) + b;
-            if (jp >= 0 && f.cmask[jp] != 0xFF) { pm &= ~(0xFFu << (8 * b)); pv &= pm; }
-            if (jn < static_cast<int>(f.len) && f.cmask[jn] != 0xFF) { nm &= ~(0xFFu << (8 * b)); nv &= nm; }
+            if (jp >= 0 && hg_factor_cmask(f, jp) != 0xFF) { pm &= ~(0xFFu << (8 * b)); pv &= pm; }
+            if (jn < static_cast<int>(f.len) && hg_factor_cmask(f, jn) != 0xFF) { nm &= ~(0xFFu << (8 * b)); nv &= nm; }
           }
         }
         // the slot keeps up to two values exactly, each with the agreement of the conditions of ITS windows
@@ -1703,7 +1738,9 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
         fct.mode = mode;
         fct.mode_rank = rank;
         std::memcpy(fct.lit, l.bytes.data(), fct.len);
-        std::memcpy(fct.cmask, l.cmask.data(), fct.len);
+        for (uint32_t b = 0; b < fct.len; b++)
+          if (static_cast<unsigned char>(l.cmask[b]) != 0xFF) fct.casebits |= 1u << b;
+        fct.id = db->patterns[i].id;
         db->factors.push_back(fct);
       }
     }

@@ -52,6 +52,8 @@ struct HgDbView {
   const uint16_t *disc;          // GPU verify pass: discriminated buckets (hg_db.h)
   const uint32_t *bucket_off2;
   const HgWindow *windows2;
+  const HgWinEntry *wtab;        // direct window table (hg_db.h)
+  uint32_t wtab_mask;
   const uint32_t *slow;
   uint32_t npatterns, nslow, fold_mask;
   uint32_t window_mask;  // 0xFFFFFFFF, or 0x00FFFFFF for 3-byte windows
@@ -135,21 +137,29 @@ template <typename Emit>
 HG_HD void hg_verify_window(const HgDbView &db, const uint8_t *text, uint64_t nbytes, uint64_t pos, uint32_t w,
                             Emit &&emit) {
   uint32_t folded = (w | db.fold_mask) & db.window_mask;
+  auto check = [&](uint32_t factor_off) {
+    uint32_t off = factor_off & 0xff;
+    const HgFactor &f = db.factors[factor_off >> 8];
+    if (pos < off) return;
+    uint64_t start = pos - off;
+    if (start + f.len > nbytes) return;
+    for (uint32_t b = 0; b < f.len; b++)
+      if ((text[start + b] ^ f.lit[b]) & hg_factor_cmask(f, b)) return;
+    emit(f.pattern, start, f.len);
+  };
+  // the direct table first: a value that is not in it belongs to no literal, a value with one owner names it
+  HgWinEntry e;
+  if (!hg_wtab_find(db.wtab, db.wtab_mask, folded, &e)) return;
+  if (e.count == 1) {
+    check(e.factor_off);
+    return;
+  }
   uint32_t j0, j1;
   hg_disc_range(db, text, nbytes, pos, folded, &j0, &j1);
   for (uint32_t j = j0; j < j1; j++) {
     HgWindow win = db.windows2[j];
     if (win.value != folded) continue;
-    uint32_t off = win.factor_off & 0xff;
-    const HgFactor &f = db.factors[win.factor_off >> 8];
-    if (pos < off) continue;
-    uint64_t start = pos - off;
-    if (start + f.len > nbytes) continue;
-    bool ok = true;
-    for (uint32_t b = 0; b < f.len; b++) {
-      if ((text[start + b] ^ f.lit[b]) & f.cmask[b]) { ok = false; break; }
-    }
-    if (ok) emit(f.pattern, start, f.len);
+    check(win.factor_off);
   }
 }
 

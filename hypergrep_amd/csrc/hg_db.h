@@ -89,7 +89,12 @@ struct HgHugeHeader {
 static_assert(sizeof(HgHugeHeader) == 64, "HgHugeHeader layout");
 
 struct HgPattern {
+  // the four words every confirm routine reads, in one 16-byte piece (the record is 80 bytes: no such piece straddles a cache line)
   uint32_t id;          // report id given by the caller
+  uint32_t single;      // HS_FLAG_SINGLEMATCH set
+  uint32_t max_len;     // longest possible match in bytes, 0 = unbounded (literal_only: the literal's length)
+  uint32_t lit_lead;    // tier 0: every match contains one of the pattern's required literals starting at most this many bytes
+                        // after the match's start (0xFFFFFFFF: no bound) — the confirm routines' window (hg_confirm_dev.h)
   uint32_t flags;       // HS_FLAG_* bits
   uint32_t nnodes;      // automaton nodes
   uint32_t nw;          // state words = ceil(nnodes / 32); more than HG_MAX_W: a huge automaton (HgHugeHeader)
@@ -99,28 +104,61 @@ struct HgPattern {
   uint32_t amask_off;   // amask[4][4][nw]  nodes whose entry condition holds for (prev ctx, ctx of own byte)
   uint32_t acc_off;     // acc[4][5][nw]    nodes that accept for (ctx of own byte, next ctx)
   uint32_t tier;        // 0: anchored by a required literal (stream prefilter + confirm); 1: always-on
-  uint32_t single;      // HS_FLAG_SINGLEMATCH set
   uint32_t simple;      // one state word and no boundary conditions: S' = (init | follow(S)) & reach[c], accept = S & acc_all
   uint32_t acc_all;     // accepting nodes when `simple`
   uint32_t init_word;   // init[0] when `simple`
   uint32_t literal_only;  // the whole expression is one literal (its factor): a verified occurrence IS the match
-  uint32_t max_len;       // longest possible match in bytes, 0 = unbounded (literal_only: the literal's length)
-  uint32_t lit_lead;      // tier 0: every match contains one of the pattern's required literals starting at most this many bytes
-                          // after the match's start (0xFFFFFFFF: no bound) — the confirm routines' window (hg_confirm_dev.h)
+  uint32_t reserved[3];
 };
-static_assert(sizeof(HgPattern) == 68, "HgPattern layout");
+static_assert(sizeof(HgPattern) == 80, "HgPattern layout");
 
-// A required literal of one pattern ("factor"): any match of the pattern contains an occurrence.
+// A required literal of one pattern ("factor"): any match of the pattern contains an occurrence.  ONE 64-byte cache line
+// (round 2: 80 bytes with a mask byte per literal byte — three to five 16-byte fetches from two lines per verified candidate).
 struct HgFactor {
   uint32_t pattern;              // index into patterns[]
   uint32_t len;                  // <= HG_FACTOR_MAX
   uint32_t mode;                 // confirm routine of the pattern (hg_confirm_mode), copied here so the verify pass needs no pattern load
   uint32_t mode_rank;            // the pattern's rank among the patterns of its confirm mode: names its verified-occurrence lists (no two
                                  // patterns of a mode share a list while the mode has at most HG_DEFER_SHARDS of them)
-  uint8_t lit[HG_FACTOR_MAX];    // literal bytes
-  uint8_t cmask[HG_FACTOR_MAX];  // 0xFF exact, 0xDF case-insensitive letter
+  uint8_t lit[HG_FACTOR_MAX];    // literal bytes (case-insensitive letters in lower case)
+  uint32_t casebits;             // bit b: byte b is a case-insensitive letter (compared under the mask 0xDF)
+  uint32_t id;                   // the pattern's report id (a literal-only expression needs nothing else of its pattern)
+  uint32_t reserved[2];
 };
-static_assert(sizeof(HgFactor) == 80, "HgFactor layout");
+static_assert(sizeof(HgFactor) == 64, "HgFactor layout");
+HG_HD uint32_t hg_factor_cmask(const HgFactor &f, uint32_t b) { return ((f.casebits >> b) & 1u) ? 0xDFu : 0xFFu; }
+// Compare mask of the literal's dword j (bytes 4 j .. 4 j + 3): 0xDF on case-insensitive letters, zero past the literal's end.
+HG_HD uint32_t hg_factor_mask_dword(uint32_t casebits, uint32_t len, uint32_t j) {
+  const uint32_t nib = (casebits >> (4u * j)) & 15u;
+  const uint32_t spread = (nib & 1u) | ((nib & 2u) << 7) | ((nib & 4u) << 14) | ((nib & 8u) << 21);
+  const uint32_t m = ~(spread << 5);
+  const uint32_t valid = len > 4u * j ? len - 4u * j : 0u;
+  return valid >= 4u ? m : (m & ((1u << (8u * valid)) - 1u));
+}
+
+// Direct window table: the folded value of a literal window -> the (literal, offset) it belongs to, in ONE 64-byte fetch
+// (a bucket of four entries; open addressing over buckets, filled front to back and never more than half full).  count == 1:
+// factor_off names the only (literal, offset) with this window; count > 1: several literals share the window, the
+// discriminated buckets (disc / bucket_off2 / windows2 below) name them; count == 0: empty.  A window value that is not in
+// the table belongs to no literal: the stream filter's false positives end here.
+struct HgWinEntry {
+  uint32_t value, factor_off, count, reserved;
+};
+static_assert(sizeof(HgWinEntry) == 16, "HgWinEntry layout");
+constexpr uint32_t HG_WTAB_WAYS = 4;
+HG_HD uint32_t hg_wtab_bucket(uint32_t folded, uint32_t bucket_mask) { return ((folded * 0x9E3779B1u) >> 9) & bucket_mask; }
+HG_HD bool hg_wtab_find(const HgWinEntry *tab, uint32_t bucket_mask, uint32_t folded, HgWinEntry *out) {
+  for (uint32_t b = hg_wtab_bucket(folded, bucket_mask);; b = (b + 1u) & bucket_mask) {
+    const HgWinEntry *e = tab + static_cast<size_t>(b) * HG_WTAB_WAYS;
+    for (uint32_t k = 0; k < HG_WTAB_WAYS; k++) {
+      if (e[k].count == 0) return false;
+      if (e[k].value == folded) {
+        *out = e[k];
+        return true;
+      }
+    }
+  }
+}
 
 // One window (HG_WINDOW_BYTES bytes) of a factor, placed at literal offset `off`; keyed by the folded, masked dword value.
 struct HgWindow {

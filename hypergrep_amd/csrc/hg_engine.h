@@ -145,6 +145,7 @@ struct HgEngineKnobs {
   uint64_t hit_limit = 0;          // HG_HIT_LIMIT (0: default 2^28)
   uint64_t cand_limit = 0;         // HG_CAND_LIMIT (0: default 2^30)
   bool verbose = false;            // HG_VERBOSE
+  bool no_literal_direct = false;  // HG_NO_LITERAL_DIRECT: literal sets through verify + confirm like any other set (A/B)
   static HgEngineKnobs from_env();
 };
 
@@ -193,7 +194,7 @@ class HgScanner {
   // database on device
   HgDbView view_{};
   std::shared_ptr<const HgDb> db_;
-  void *d_disc_ = nullptr, *d_bucket2_ = nullptr, *d_windows2_ = nullptr, *d_groups_ = nullptr;
+  void *d_disc_ = nullptr, *d_bucket2_ = nullptr, *d_windows2_ = nullptr, *d_groups_ = nullptr, *d_wtab_ = nullptr;
   void *d_patterns_ = nullptr, *d_pool_ = nullptr, *d_factors_ = nullptr, *d_windows_ = nullptr, *d_bucket_ = nullptr,
        *d_filter_ = nullptr, *d_ext_ = nullptr, *d_slow_ = nullptr;
   // workspace
@@ -235,6 +236,7 @@ class HgScanner {
   // fin_fallback_: a bucket outgrew what one block sorts, the compact array + library sort is used from then on
   uint32_t *d_fin_fill_ = nullptr, *d_fin_kept_ = nullptr, *d_fin_total_ = nullptr, *d_fin_big_ = nullptr;
   bool fin_fallback_ = false;
+  uint32_t fin_epoch_ = 0;  // hg_fin_scan_kernel: a fresh value per launch marks the blocks' partial sums as this launch's
   uint64_t fin_expect_hits_ = 0;  // raw hits of the last pass: the next one picks its bucket count for ~24 records a bucket
   void *d_huge_claim_ = nullptr;      // huge automata: (piece start, expression) pairs already run (hg_confirm_huge_kernel), 8-byte slots
   uint64_t huge_claim_slots_ = 0;

@@ -39,7 +39,9 @@ template <uint32_t LCAP, bool IN_LDS>
 __global__ void hg_fin_sort_big_kernel(const HgHit *hits, uint32_t *idx, const uint32_t *fill, const uint32_t *big_list, const uint32_t *big_count, uint32_t cap,
                                        uint32_t id_bits, uint32_t to_bits, uint32_t *kept_count, uint32_t *overflow, uint64_t *scratch_key, uint32_t *scratch_idx);
 template <uint32_t THREADS>
-__global__ void hg_fin_scan_kernel(uint32_t *kept_count, uint32_t b_lo, uint32_t b_hi, uint32_t *total, const uint32_t *fill, uint32_t cap);
+__global__ void hg_fin_scan_kernel(uint32_t *kept_count, uint32_t b_lo, uint32_t b_hi, uint32_t *total, const uint32_t *fill, uint32_t cap, uint32_t *part, uint32_t epoch);
+__global__ void hg_confirm_literal_kernel(HgConfirmArgs a);
+__global__ void hg_literal_kernel(HgConfirmArgs a);
 __global__ void hg_fin_gather_kernel(const HgHit *hits, const HgHitAux *aux, const uint32_t *idx, const uint32_t *kept_base, const uint32_t *total, uint32_t b_lo,
                                      uint32_t b_hi, uint32_t cap, HgHit *oh, HgHitAux *oa);
 __global__ void hg_key_kernel(const HgHit *hits, const HgHitAux *aux, const HgPattern *patterns, uint32_t n, uint64_t *key, uint32_t *idx);
@@ -97,6 +99,7 @@ HgEngineKnobs HgEngineKnobs::from_env() {
   k.hit_limit = num("HG_HIT_LIMIT", 0);
   k.cand_limit = num("HG_CAND_LIMIT", 0);
   k.verbose = std::getenv("HG_VERBOSE") != nullptr;
+  k.no_literal_direct = std::getenv("HG_NO_LITERAL_DIRECT") != nullptr;
   return k;
 }
 
@@ -143,6 +146,7 @@ int HgScanner::create(std::shared_ptr<const HgDb> db, int device, HgScanner **ou
   HG_TRY(upload(&s->d_disc_, db->disc, "d_disc_"), "upload discriminators");
   HG_TRY(upload(&s->d_bucket2_, db->bucket_off2, "d_bucket2_"), "upload buckets");
   HG_TRY(upload(&s->d_windows2_, db->windows2, "d_windows2_"), "upload windows");
+  HG_TRY(upload(&s->d_wtab_, db->wtab, "d_wtab_"), "upload window table");
   HG_TRY(upload(&s->d_filter_, db->filter, "d_filter_"), "upload filter");
   HG_TRY(upload(&s->d_ext_, db->ext, "d_ext_"), "upload filter conditions");
   HG_TRY(upload(&s->d_slow_, db->slow, "d_slow_"), "upload always-on list");
@@ -155,6 +159,8 @@ int HgScanner::create(std::shared_ptr<const HgDb> db, int device, HgScanner **ou
   s->view_.disc = static_cast<const uint16_t *>(s->d_disc_);
   s->view_.bucket_off2 = static_cast<const uint32_t *>(s->d_bucket2_);
   s->view_.windows2 = static_cast<const HgWindow *>(s->d_windows2_);
+  s->view_.wtab = static_cast<const HgWinEntry *>(s->d_wtab_);
+  s->view_.wtab_mask = db->wtab_mask;
   s->view_.slow = static_cast<const uint32_t *>(s->d_slow_);
   s->view_.npatterns = static_cast<uint32_t>(db->patterns.size());
   s->view_.nslow = static_cast<uint32_t>(db->slow.size());
@@ -192,7 +198,7 @@ HgScanner::~HgScanner() {
   (void)hipSetDevice(device_);
   void *ptrs[] = {d_patterns_, d_pool_, d_factors_, d_windows_, d_bucket_, d_filter_, d_ext_, d_slow_, d_sums_, d_bases_, d_block_base_,
                   d_agg_, d_cands_, d_hits_raw_, d_hits_out_, d_aux_raw_, d_aux_out_,
-                  d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, d_keep_, d_counters_, d_temp_, d_seg_count_, d_pflags_, d_deferred_, d_defer_count_, d_seg_count2_, d_cands2_, d_disc_, d_bucket2_, d_windows2_, d_groups_, d_acc_hits_, d_acc_aux_, d_huge_claim_};
+                  d_key_a_, d_key_b_, d_perm_a_, d_perm_b_, d_keep_, d_counters_, d_temp_, d_seg_count_, d_pflags_, d_deferred_, d_defer_count_, d_seg_count2_, d_cands2_, d_disc_, d_bucket2_, d_windows2_, d_groups_, d_acc_hits_, d_acc_aux_, d_huge_claim_, d_wtab_};
   for (void *p : ptrs) hgmem::dev_free(p, "scanner");
   hgmem::host_free(h_counters_, "h_counters_");
   for (auto &ev : ev_)
@@ -321,7 +327,8 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   if (ntiles && !d_fin_fill_ && !fin_fallback_) {
     HG_TRY(hgmem::dev_alloc(&d_fin_fill_, HG_FIN_MAX_BUCKETS * 4, "d_fin_fill_"), "alloc finalize buckets");
     HG_TRY(hgmem::dev_alloc(&d_fin_kept_, HG_FIN_MAX_BUCKETS * 4, "d_fin_kept_"), "alloc finalize buckets");
-    HG_TRY(hgmem::dev_alloc(&d_fin_big_, 2 * HG_FIN_MAX_BUCKETS * 4, "d_fin_big_"), "alloc finalize buckets");  // (two work lists)
+    HG_TRY(hgmem::dev_alloc(&d_fin_big_, (2 * HG_FIN_MAX_BUCKETS + 3 * 128) * 4, "d_fin_big_"), "alloc finalize buckets");  // (two work lists + the scan's partial sums)
+    HG_TRY(hipMemsetAsync(d_fin_big_ + 2 * HG_FIN_MAX_BUCKETS, 0, 3 * 128 * 4, stream), "clear scan flags");
   }
   const bool bucketed = ntiles && d_fin_fill_ && fin_cap && fin_shift <= 64 - HG_HIT_REL_SHIFT && fin_shift + id_bits + to_bits + 1 <= 64 &&
                         bits_for(line_base + nbytes + 1) <= HG_HIT_REL_SHIFT && !fin_fallback_ && !knobs_.no_bucket_finalize;
@@ -435,8 +442,12 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       if (big_blocks)
         hipLaunchKernelGGL((hg_fin_sort_big_kernel<HG_FIN_BUCKET_CAP, false>), dim3(big_blocks), dim3(256), 0, s, d_hits_raw_, d_perm_a_, d_fin_fill_, d_fin_big_ + HG_FIN_MAX_BUCKETS,
                            d_fin_total_ + 3, fin_cap, id_bits, to_bits, d_fin_kept_, d_selected_ + 1, d_key_a_, d_perm_b_);
-      if (beside_stream) hipLaunchKernelGGL(hg_fin_scan_kernel<512u>, dim3(1), dim3(512), 0, s, d_fin_kept_, lo, hi, d_fin_total_, d_fin_fill_, fin_cap);
-      else hipLaunchKernelGGL(hg_fin_scan_kernel<1024u>, dim3(1), dim3(1024), 0, s, d_fin_kept_, lo, hi, d_fin_total_, d_fin_fill_, fin_cap);
+      // (a block per 8192 buckets, 128 at most: their partial sums live behind the two work lists)
+      const uint32_t scan_blocks = std::max<uint32_t>(1, std::min<uint32_t>(128, (nbk + 8191) / 8192));
+      uint32_t *part = d_fin_big_ + 2 * HG_FIN_MAX_BUCKETS;
+      const uint32_t epoch = ++fin_epoch_ ? fin_epoch_ : ++fin_epoch_;  // (never 0: the flags start out zeroed)
+      if (beside_stream) hipLaunchKernelGGL(hg_fin_scan_kernel<512u>, dim3(scan_blocks), dim3(512), 0, s, d_fin_kept_, lo, hi, d_fin_total_, d_fin_fill_, fin_cap, part, epoch);
+      else hipLaunchKernelGGL(hg_fin_scan_kernel<1024u>, dim3(scan_blocks), dim3(1024), 0, s, d_fin_kept_, lo, hi, d_fin_total_, d_fin_fill_, fin_cap, part, epoch);
       hipLaunchKernelGGL(hg_fin_gather_kernel, dim3(std::min<uint32_t>((nbk + 3) / 4, cu * 8)), dim3(256), 0, s, d_hits_raw_, d_aux_raw_, d_perm_a_, d_fin_kept_, d_fin_total_, lo, hi, fin_cap,
                          d_hits_out_, d_aux_out_);
       HG_TRY(hipGetLastError(), "finalize launch");
@@ -576,8 +587,14 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
             ca.list_spread[m] = std::min<uint32_t>(HG_DEFER_SHARDS, std::max<uint32_t>(1, HG_DEFER_SHARDS / std::max<uint32_t>(1, db_->n_confirm_mode[m])) * defer_spread_boost_);
           }
           if (c > 0) HG_TRY(hipMemsetAsync(d_defer_count_, 0, HG_CONFIRM_MODES * HG_DEFER_SHARDS * 4, side), "memset deferred counts");  // (chunk 0: hg_reset_kernel)
-          hipLaunchKernelGGL(hg_verify_kernel, dim3(verify_blocks), dim3(256), 0, side, ca);
-          if (fast_modes) hipLaunchKernelGGL(hg_confirm_fast_kernel, dim3(mode_blocks * fast_modes), dim3(HG_CONFIRM_THREADS), 0, side, ca, mode_blocks);
+          // (a set of literals whose windows each have one owner: window -> hit in one kernel, no lists: hg_literal_kernel)
+          const bool direct = db_->literal_direct && !knobs_.no_literal_direct;
+          if (direct) hipLaunchKernelGGL(hg_literal_kernel, dim3(verify_blocks), dim3(256), 0, side, ca);
+          else hipLaunchKernelGGL(hg_verify_kernel, dim3(verify_blocks), dim3(256), 0, side, ca);
+          const bool literal_only_set = ca.mode_present[0] && !ca.mode_present[1] && !ca.mode_present[2];
+          if (direct) {
+          } else if (literal_only_set) hipLaunchKernelGGL(hg_confirm_literal_kernel, dim3(mode_blocks), dim3(256), 0, side, ca);  // (blocks of 256: as many lanes per CU as before)
+          else if (fast_modes) hipLaunchKernelGGL(hg_confirm_fast_kernel, dim3(mode_blocks * fast_modes), dim3(HG_CONFIRM_THREADS), 0, side, ca, mode_blocks);
           if (db_->n_confirm_mode[3]) hipLaunchKernelGGL(hg_confirm_generic_kernel, dim3(mode_blocks), dim3(256), 0, side, ca);
           if (huge_blocks && ((mode_mask >> 4) & 1u)) {
             HG_TRY(hipMemsetAsync(d_huge_claim_, 0, huge_claim_slots_ * 8, side), "memset claim table");

@@ -869,6 +869,77 @@ __device__ __forceinline__ void verify_stage_flush(const HgConfirmArgs &a, Verif
   __syncthreads();
 }
 
+// Direct window table lookup (hg_db.h HgWinEntry), a bucket of four entries with ONE cache-line fetch.  Returns the entry's
+// count (0: the value belongs to no literal) and its factor_off.
+__device__ __forceinline__ uint32_t wtab_lookup(const HgWinEntry *tab, uint32_t bucket_mask, uint32_t folded, uint32_t *factor_off) {
+  for (uint32_t b = hg_wtab_bucket(folded, bucket_mask);; b = (b + 1u) & bucket_mask) {
+    const uint4 *e = reinterpret_cast<const uint4 *>(tab + static_cast<size_t>(b) * HG_WTAB_WAYS);
+    const uint4 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];  // {value, factor_off, count, -}
+    if (e0.z && e0.x == folded) { *factor_off = e0.y; return e0.z; }
+    if (e1.z && e1.x == folded) { *factor_off = e1.y; return e1.z; }
+    if (e2.z && e2.x == folded) { *factor_off = e2.y; return e2.z; }
+    if (e3.z && e3.x == folded) { *factor_off = e3.y; return e3.z; }
+    if (!e3.z) return 0;  // the bucket has room left: the value would be here (buckets fill front to back)
+  }
+}
+// Does the literal of `f` (len bytes, HgFactor) occur at text[fs, fs + len)?  The record is one cache line: the literal as
+// 16-byte pieces, the compare masks from its case bits; the text unaligned.  fs + len <= nbytes.
+__device__ __forceinline__ bool literal_occurs(const HgFactor *f, uint32_t len, const uint8_t *text, uint64_t fs, uint64_t readable, bool folding) {
+  const uint8_t *tp = text + fs;
+  const uint32_t cb = folding ? f->casebits : 0u;
+  uint32_t diff = 0;
+  if (fs + (len > 16 ? 32u : 16u) <= readable) {
+    const uint4 l0 = *reinterpret_cast<const uint4 *>(f->lit);
+    const hg_u32x4_unaligned x0 = *reinterpret_cast<const hg_u32x4_unaligned *>(tp);
+    diff = ((x0[0] ^ l0.x) & hg_factor_mask_dword(cb, len, 0)) | ((x0[1] ^ l0.y) & hg_factor_mask_dword(cb, len, 1)) |
+           ((x0[2] ^ l0.z) & hg_factor_mask_dword(cb, len, 2)) | ((x0[3] ^ l0.w) & hg_factor_mask_dword(cb, len, 3));
+    if (len > 16) {
+      const uint4 l1 = *reinterpret_cast<const uint4 *>(f->lit + 16);
+      const hg_u32x4_unaligned x1 = *reinterpret_cast<const hg_u32x4_unaligned *>(tp + 16);
+      diff |= ((x1[0] ^ l1.x) & hg_factor_mask_dword(cb, len, 4)) | ((x1[1] ^ l1.y) & hg_factor_mask_dword(cb, len, 5)) |
+              ((x1[2] ^ l1.z) & hg_factor_mask_dword(cb, len, 6)) | ((x1[3] ^ l1.w) & hg_factor_mask_dword(cb, len, 7));
+    }
+  } else {  // the last bytes of the buffer: byte compares
+    for (uint32_t b = 0; b < len; b++) diff |= (tp[b] ^ f->lit[b]) & (((cb >> b) & 1u) ? 0xDFu : 0xFFu);
+  }
+  return diff == 0;
+}
+
+// Pattern sets of SINGLEMATCH literals whose windows each belong to ONE (literal, offset) (HgDb::literal_direct: config 5's 4096
+// literals, a single keyword): a candidate goes from window to hit in one lane's straight line — table bucket -> literal record
+// + text -> line geometry -> report — instead of through the verify pass, a verified-occurrence list and a confirm pass.
+// The line's bytes around the occurrence are fetched once (the walk's first chunk is the line the compare just read).
+__global__ __launch_bounds__(256) void hg_literal_kernel(HgConfirmArgs a) {
+  __shared__ uint32_t s_n, s_base;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
+  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n};
+  const uint32_t seg = blockIdx.x / HG_CONFIRM_SPLIT, sub = blockIdx.x % HG_CONFIRM_SPLIT;
+  const HgCand *cseg = a.cands + static_cast<uint64_t>(seg) * a.cand_seg_cap;
+  uint32_t n = a.seg_count[seg];
+  if (n > a.cand_seg_cap) n = a.cand_seg_cap;
+  const uint32_t fold = a.db.fold_mask;
+  const uint64_t readable = (a.nbytes + 15) & ~15ull;
+  for (uint32_t i = sub * 256u + threadIdx.x; i < n; i += HG_CONFIRM_SPLIT * 256u) {
+    const HgCand c = cseg[i];
+    const uint32_t folded = (c.word | fold) & a.db.window_mask;
+    uint32_t fo = 0;
+    if (!wtab_lookup(a.db.wtab, a.db.wtab_mask, folded, &fo)) continue;
+    const uint32_t off = fo & 0xffu;
+    const HgFactor *f = &a.db.factors[fo >> 8];
+    const uint4 hdr = *reinterpret_cast<const uint4 *>(f);  // pattern, len, mode, mode_rank
+    const uint32_t len = hdr.y;
+    if (c.pos < off || c.pos - off + len > a.nbytes) continue;
+    const uint64_t fs = c.pos - off;
+    if (!literal_occurs(f, len, a.text, fs, readable, fold != 0)) continue;
+    const uint32_t id = f->id, pattern = hdr.x;
+    hgdev::confirm_literal(a.text, a.nbytes, a.sums, a.bases, a.bs1, c.pos, c.rank, fs, len,
+                           [&](uint64_t line_no, uint32_t to, uint64_t start, uint32_t llen) { sink.push(a, line_no, id, to, start, llen, pattern, true); });
+  }
+  flush_hits(a, &s_n, &s_base);
+}
+
 __global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
   __shared__ VerifyStage s_stage;
   if (threadIdx.x == 0) s_stage.n = 0;
@@ -893,10 +964,19 @@ __global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
     const uint32_t base = base0 + wave * 64u;
     const uint32_t i = base + lane;
     HgCand c{0, 0, 0};
-    uint32_t j0 = 0, cnt = 0, folded = 0;
+    uint32_t j0 = 0, cnt = 0, folded = 0, direct_fo = 0;
+    bool direct = false, shared = false;
     if (i < n) {
       c = cseg[i];
       folded = (c.word | fold) & a.db.window_mask;
+      // the direct table: a value it does not hold belongs to no literal (the filter's false positives end here, one fetch
+      // each); a value with one owner names it; only windows that several literals share go through the discriminated buckets
+      const uint32_t owners = wtab_lookup(a.db.wtab, a.db.wtab_mask, folded, &direct_fo);
+      direct = owners == 1;
+      shared = owners > 1;
+      if (direct) cnt = 1;
+    }
+    if (shared) {
       // the group's discriminator dword of the text selects the bucket (hg_disc_range, with one aligned dword load)
       const uint32_t h = hg_hash_window(folded);
       const uint32_t d = a.db.disc[h];
@@ -944,33 +1024,22 @@ __global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
         if (probe < 64u && sp <= t) owner = probe;
       }
       const uint32_t o_start = __shfl(start, owner, 64), o_j0 = __shfl(j0, owner, 64), o_folded = __shfl(folded, owner, 64);
+      const uint32_t o_direct = __shfl(direct ? 1u : 0u, owner, 64), o_fo = __shfl(direct_fo, owner, 64);
       const uint32_t o_rank = __shfl(c.rank, owner, 64);
       const uint64_t pos = (static_cast<uint64_t>(static_cast<uint32_t>(__shfl(pos_hi, owner, 64))) << 32) | static_cast<uint32_t>(__shfl(pos_lo, owner, 64));
       bool ok = false;
       uint32_t mode = 0, tag = 0, mode_rank = 0;
       if (t < total) {
-        const HgWindow win = a.db.windows2[o_j0 + (t - o_start)];
+        HgWindow win{o_folded, o_fo};
+        if (!o_direct) win = a.db.windows2[o_j0 + (t - o_start)];
         if (win.value == o_folded) {
           const uint32_t off = win.factor_off & 0xffu;
           const HgFactor *f = &a.db.factors[win.factor_off >> 8];
-          const uint4 hdr = *reinterpret_cast<const uint4 *>(f);  // pattern, len, mode, pad
+          const uint4 hdr = *reinterpret_cast<const uint4 *>(f);  // pattern, len, mode, mode_rank
           const uint32_t len = hdr.y;
           if (pos >= off && pos - off + len <= a.nbytes) {
             const uint64_t fs = pos - off;
-            const uint8_t *tp = a.text + fs;
-            uint32_t diff = 0;
-            if (fs + (len > 16 ? 32u : 16u) <= readable) {
-              const uint4 l0 = *reinterpret_cast<const uint4 *>(f->lit), m0 = *reinterpret_cast<const uint4 *>(f->cmask);
-              const hg_u32x4_unaligned x0 = *reinterpret_cast<const hg_u32x4_unaligned *>(tp);
-              diff = ((x0[0] ^ l0.x) & m0.x) | ((x0[1] ^ l0.y) & m0.y) | ((x0[2] ^ l0.z) & m0.z) | ((x0[3] ^ l0.w) & m0.w);  // cmask is zero past len
-              if (len > 16) {
-                const uint4 l1 = *reinterpret_cast<const uint4 *>(f->lit + 16), m1 = *reinterpret_cast<const uint4 *>(f->cmask + 16);
-                const hg_u32x4_unaligned x1 = *reinterpret_cast<const hg_u32x4_unaligned *>(tp + 16);
-                diff |= ((x1[0] ^ l1.x) & m1.x) | ((x1[1] ^ l1.y) & m1.y) | ((x1[2] ^ l1.z) & m1.z) | ((x1[3] ^ l1.w) & m1.w);
-              }
-            } else {  // the last bytes of the buffer: byte compares
-              for (uint32_t b = 0; b < len; b++) diff |= (tp[b] ^ f->lit[b]) & f->cmask[b];
-            }
+            const uint32_t diff = literal_occurs(f, len, a.text, fs, readable, fold != 0) ? 0u : 1u;
             if (diff == 0) {
               ok = true;
               mode = hdr.z;
@@ -1220,6 +1289,10 @@ __global__ __launch_bounds__(HG_CONFIRM_THREADS) void hg_confirm_fast_kernel(HgC
 #endif
 }
 __global__ __launch_bounds__(256) void hg_confirm_generic_kernel(HgConfirmArgs a) { confirm_body<3>(a, blockIdx.x, gridDim.x); }
+// Pattern sets whose anchored expressions are ALL literal-only (config 5's 4096 literals, a single keyword): the routine on its
+// own, at a third of the registers of the three-routine kernel — the pass is a chain of dependent loads per occurrence, and
+// resident waves are what hides them.
+__global__ __launch_bounds__(256) void hg_confirm_literal_kernel(HgConfirmArgs a) { confirm_body<0>(a, blockIdx.x, gridDim.x); }
 
 // Scalar always-on pass over the entries [first, last) of the always-on list (patterns of more than two state words).
 __global__ __launch_bounds__(256) void hg_always_on_kernel(HgConfirmArgs a, uint32_t first, uint32_t last) {
@@ -2037,23 +2110,30 @@ template __global__ void hg_fin_sort_big_kernel<HG_FIN_MEDIUM_CAP, true>(const H
                                                                           uint32_t *, uint32_t *, uint64_t *, uint32_t *);
 template __global__ void hg_fin_sort_big_kernel<HG_FIN_BUCKET_CAP, false>(const HgHit *, uint32_t *, const uint32_t *, const uint32_t *, const uint32_t *, uint32_t, uint32_t, uint32_t,
                                                                            uint32_t *, uint32_t *, uint64_t *, uint32_t *);
-// One block: kept_count[b_lo, b_hi) -> exclusive positions in the compact output, continuing from *total (the kept records of
-// the bucket ranges finalized before); *total moves on.
-// (THREADS: 1024 when the finalize has the chip to itself or shares it with side passes; 512 beside the stream pass, where a
-// block of 1024 does not fit on a CU next to two stream workgroups and waited for the launch to end)
+// kept_count[b_lo, b_hi) -> exclusive positions in the compact output, continuing from *total (the kept records of the bucket
+// ranges finalized before); *total moves on.  total[0] += kept records of the range, total[1] += raw records of the range (fill
+// levels, a bucket holds at most cap).
+// A grid of blocks, each with a contiguous span of the range (round 2: ONE block walked the whole range — 440 us for config 5's
+// million buckets, twice per pass): a block sums its span, publishes the sums (part[] + a flag holding this launch's epoch),
+// adds up the sums of the blocks before it as they appear, and rescans its span into positions.  A block only ever waits for
+// blocks with LOWER indices, which were dispatched before it: no deadlock whatever shares the chip.
+// part: 3 * gridDim.x words {kept sum, raw sum, flag}; epoch: a value no earlier launch on these words has used.
 template <uint32_t HG_FIN_SCAN_THREADS>
 __global__ __launch_bounds__(HG_FIN_SCAN_THREADS) void hg_fin_scan_kernel(uint32_t *kept_count, uint32_t b_lo, uint32_t b_hi, uint32_t *total, const uint32_t *fill,
-                                                                          uint32_t cap) {
-  // total[0] += kept records of the range, total[1] += raw records of the range (fill levels, a bucket holds at most cap)
-  __shared__ uint32_t s_wave[HG_FIN_SCAN_THREADS / 64], s_raw[HG_FIN_SCAN_THREADS / 64];
+                                                                          uint32_t cap, uint32_t *part, uint32_t epoch) {
+  __shared__ uint32_t s_wave[HG_FIN_SCAN_THREADS / 64], s_raw[HG_FIN_SCAN_THREADS / 64], s_base[2];
   constexpr uint32_t WAVES = HG_FIN_SCAN_THREADS / 64;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const uint32_t carry = *total;
-  // wave w owns a contiguous share of the range and walks it 64 entries at a time (coalesced): first the share's sum ...
-  const uint32_t share = ((b_hi - b_lo + WAVES - 1) / WAVES + 63u) & ~63u;
-  const uint32_t w_lo = b_lo + wave * share, w_hi = w_lo + share < b_hi ? w_lo + share : b_hi;
+  const uint32_t carry = total[0], carry_raw = total[1];
+  // this block's span (a multiple of 64 buckets per wave), wave w a contiguous share of it
+  const uint32_t nb = b_hi - b_lo;
+  const uint32_t span = (((nb + gridDim.x - 1) / gridDim.x + WAVES * 64u - 1) / (WAVES * 64u)) * (WAVES * 64u);
+  const uint32_t s_lo = b_lo + (blockIdx.x * span < nb ? blockIdx.x * span : nb);
+  const uint32_t s_hi = s_lo + span < b_hi ? s_lo + span : b_hi;
+  const uint32_t share = span / WAVES;
+  const uint32_t w_lo = s_lo + wave * share < s_hi ? s_lo + wave * share : s_hi, w_hi = w_lo + share < s_hi ? w_lo + share : s_hi;
   uint32_t sum = 0, raw = 0;
-#pragma unroll 8
+#pragma unroll 4
   for (uint32_t i = w_lo + lane; i < w_hi; i += 64) {
     sum += kept_count[i];
     const uint32_t f = fill[i];
@@ -2065,8 +2145,8 @@ __global__ __launch_bounds__(HG_FIN_SCAN_THREADS) void hg_fin_scan_kernel(uint32
     s_wave[wave] = sum;
     s_raw[wave] = raw;
   }
-  __syncthreads();  // (also: everyone has read *total before thread 0 rewrites it)
-  uint32_t run = carry, all = 0, all_raw = 0;
+  __syncthreads();  // (also: every thread has read total[] before anyone can rewrite it — the last block does, after all flags are up)
+  uint32_t run = 0, all = 0, all_raw = 0;
 #pragma unroll
   for (uint32_t w = 0; w < WAVES; w++) {
     const uint32_t t = s_wave[w];
@@ -2074,6 +2154,28 @@ __global__ __launch_bounds__(HG_FIN_SCAN_THREADS) void hg_fin_scan_kernel(uint32
     all += t;
     all_raw += s_raw[w];
   }
+  if (threadIdx.x == 0) {
+    part[3 * blockIdx.x] = all;
+    part[3 * blockIdx.x + 1] = all_raw;
+    __threadfence();
+    __hip_atomic_store(&part[3 * blockIdx.x + 2], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (wave == 0) {  // the sums of the blocks before this one
+    uint32_t before = 0, before_raw = 0;
+    for (uint32_t p = lane; p < blockIdx.x; p += 64) {
+      while (__hip_atomic_load(&part[3 * p + 2], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(2);
+      before += __hip_atomic_load(&part[3 * p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      before_raw += __hip_atomic_load(&part[3 * p + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    before = wave_inclusive_scan(before, lane);
+    before_raw = wave_inclusive_scan(before_raw, lane);
+    if (lane == 63) {
+      s_base[0] = before;
+      s_base[1] = before_raw;
+    }
+  }
+  __syncthreads();
+  run += carry + s_base[0];
   // ... then the exclusive positions (the entries come from the cache this time)
   for (uint32_t i0 = w_lo; i0 < w_hi; i0 += 64) {
     const uint32_t i = i0 + lane;
@@ -2082,13 +2184,13 @@ __global__ __launch_bounds__(HG_FIN_SCAN_THREADS) void hg_fin_scan_kernel(uint32
     if (i < w_hi) kept_count[i] = run + incl - c;
     run += __builtin_amdgcn_readlane(incl, 63);
   }
-  if (threadIdx.x == 0) {
-    total[0] = carry + all;
-    total[1] += all_raw;
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {  // (every block has published, hence read total[], by now)
+    total[0] = carry + s_base[0] + all;
+    total[1] = carry_raw + s_base[1] + all_raw;
   }
 }
-template __global__ void hg_fin_scan_kernel<512u>(uint32_t *, uint32_t, uint32_t, uint32_t *, const uint32_t *, uint32_t);
-template __global__ void hg_fin_scan_kernel<1024u>(uint32_t *, uint32_t, uint32_t, uint32_t *, const uint32_t *, uint32_t);
+template __global__ void hg_fin_scan_kernel<512u>(uint32_t *, uint32_t, uint32_t, uint32_t *, const uint32_t *, uint32_t, uint32_t *, uint32_t);
+template __global__ void hg_fin_scan_kernel<1024u>(uint32_t *, uint32_t, uint32_t, uint32_t *, const uint32_t *, uint32_t, uint32_t *, uint32_t);
 // kept records of bucket b (idx[b * cap ...] in final order) -> out[kept_base[b] ...]; bucket b + 1's base (or *total for the
 // last bucket of the range) ends the run.  One wave per bucket, grid-stride.
 __global__ void hg_fin_gather_kernel(const HgHit *hits, const HgHitAux *aux, const uint32_t *idx, const uint32_t *kept_base, const uint32_t *total, uint32_t b_lo,

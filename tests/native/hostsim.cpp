@@ -106,8 +106,18 @@ uint32_t hgsim_selfcheck(void *h, uint32_t *out) {
     bool found = false;
     for (uint32_t j = j0; j < j1; j++) found = found || (db->windows2[j].value == w.value && db->windows2[j].factor_off == w.factor_off);
     if (!found) bad++;
+    // (4) the direct table holds the window's value; with one owner it names exactly this (literal, offset)
+    HgWinEntry e;
+    if (!hg_wtab_find(db->wtab.data(), db->wtab_mask, w.value, &e) || (e.count == 1 && e.factor_off != w.factor_off)) bad++;
   }
   if (out) { out[0] = db->filter_log2; out[1] = db->filter_wide; out[2] = many; out[3] = db->dense; }
+  // the table's buckets fill front to back and are never more than half full over all
+  size_t used = 0;
+  for (size_t i = 0; i < db->wtab.size(); i++) {
+    used += db->wtab[i].count ? 1 : 0;
+    if (i % HG_WTAB_WAYS && db->wtab[i].count && !db->wtab[i - 1].count) bad++;
+  }
+  if (used * 2 > db->wtab.size() || (db->wtab.size() / HG_WTAB_WAYS) != static_cast<size_t>(db->wtab_mask) + 1) bad++;
   return bad;
 }
 uint32_t hgsim_pattern_tier(void *h, uint32_t i) { return static_cast<HgDb *>(h)->patterns[i].tier; }
@@ -134,6 +144,8 @@ static HgDbView view_of(HgDb *db) {
   v.disc = db->disc.data();
   v.bucket_off2 = db->bucket_off2.data();
   v.windows2 = db->windows2.data();
+  v.wtab = db->wtab.data();
+  v.wtab_mask = db->wtab_mask;
   v.slow = db->slow.data();
   v.npatterns = db->patterns.size();
   v.nslow = db->slow.size();

@@ -493,10 +493,13 @@ def test_full_size_properties_32gib(torch_cuda, monkeypatch):
     torch.cuda.synchronize()
     newlines = sum(int((text[o:min(o + (4 << 30), nbytes)] == 10).sum()) for o in range(0, nbytes, 4 << 30))
     db = device.Database(patterns, ids=ids)
-    db.tune(bytes(text[: 4 << 20].cpu().numpy()))
-    sc = device.Scanner(db, 0)
+    # tuned as the file API tunes by itself (hg_shim.hip maybe_tune) and as bench.py does: four pieces of 256 KiB spread over the
+    # first 256 MiB
+    db.tune(b"".join(bytes(text[(i * (64 << 20)) & ~15: ((i * (64 << 20)) & ~15) + (256 << 10)].cpu().numpy()) for i in range(4)))
+    scanners = [device.Scanner(db, 0)]
 
     def run():
+        sc = scanners[0]
         st = sc.scan(text.data_ptr(), nbytes)
         buf = torch.empty((st.n_hits, 2), dtype=torch.int64, device="cuda:0")
         assert sc.copy_hits_to(buf.data_ptr(), st.n_hits) == st.n_hits
@@ -516,6 +519,7 @@ def test_full_size_properties_32gib(torch_cuda, monkeypatch):
     st2, b = run()
     assert st2.n_hits == st.n_hits and bool((a == b).all())  # idempotent
     monkeypatch.setenv("HG_CHUNK_TILES", str(1 << 30))  # one pass, no side stream
+    scanners[0] = device.Scanner(db, 0)  # (a scanner reads the engine's knobs when it is created)
     st3, c = run()
     assert st3.stream_launches == 1 and st3.n_hits == st.n_hits and st3.n_lines == st.n_lines and bool((a == c).all())
     monkeypatch.delenv("HG_CHUNK_TILES")
@@ -524,7 +528,7 @@ def test_full_size_properties_32gib(torch_cuda, monkeypatch):
     host = bytes(text[:head_n].cpu().numpy())
     head_n = host.rfind(b"\n") + 1
     want, nl = oracle_hits(host[:head_n], patterns, ids=ids)
-    got = [h[:3] for h in sc.hits(limit=len(want) + 16) if h[0] < nl]
+    got = [h[:3] for h in scanners[0].hits(limit=len(want) + 16) if h[0] < nl]
     assert sorted(got) == [w[:3] for w in want]
 
 
@@ -585,9 +589,9 @@ def test_chunked_pipeline_equals_single_pass(torch_cuda, monkeypatch, mib, chunk
     torch.cuda.synchronize()
     db = device.Database(patterns, ids=ids)
     assert db.info()["byte_windows"] == (1 if extra else 0)
-    sc = device.Scanner(db, 0)
 
     def run():
+        sc = device.Scanner(db, 0)  # (a scanner reads the engine's knobs — HG_CHUNK_TILES below — when it is created)
         st = sc.scan(text.data_ptr(), nbytes, line_base=77)
         buf = torch.empty((st.n_hits, 2), dtype=torch.int64, device="cuda:0")
         sc.copy_hits_to(buf.data_ptr(), st.n_hits)
@@ -944,6 +948,33 @@ def test_no_kernel_reads_past_the_text(torch_cuda):
     violation is a GPU memory fault."""
     res = _run_gpu_cases("guarded")
     assert res["ok"] and res["cases"] >= 70, res
+
+
+@pytest.mark.parametrize("name", ["c2", "c3", "c5"])
+def test_benchmark_workloads_against_python_re(torch_cuda, name):
+    """A second checker that is NOT the oracle: the HIP path on 64 MiB of each benchmark workload against Python `re` run per
+    expression over the same bytes (tests/re_check.py), compared as sets of (line, expression); line count against a byte
+    count.  The CPU side of the same check (oracle vs `re`): tests/test_re_crosscheck.py."""
+    import re_check
+    from hypergrep_amd import benchspec, device
+
+    torch = torch_cuda
+    spec = {"c2": benchspec.c2_spec, "c3": benchspec.c3_spec, "c5": benchspec.c5_spec}[name]
+    patterns, needles, hpm = spec()
+    ids = list(range(len(patterns)))
+    nbytes = 64 << 20
+    text = torch.empty(nbytes + 64, dtype=torch.uint8, device="cuda:0")
+    device.synth_device(text.data_ptr(), nbytes, benchspec.SEED_BASE + int(name[1]), needles, hpm)
+    torch.cuda.synchronize()
+    host = bytes(text[:nbytes].cpu().numpy())
+    sc = device.Scanner(device.Database(patterns, ids=ids), 0)
+    st = sc.scan(text.data_ptr(), nbytes)
+    got = {(h[0], h[1]) for h in sc.hits()}
+    want = re_check.literal_line_id_pairs(host, patterns) if name == "c5" else re_check.line_id_pairs(host, patterns)
+    assert st.n_lines == host.count(b"\n") + (0 if host.endswith(b"\n") else 1)
+    assert got == want, (len(got), len(want), sorted(got - want)[:5], sorted(want - got)[:5])
+    assert len(want) > {"c2": 3000, "c3": 3000, "c5": 40000}[name]
+    assert _loaded_native()
 
 
 def test_huge_patterns_match_oracle(torch_cuda):

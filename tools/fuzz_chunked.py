@@ -49,13 +49,13 @@ while time.time() - t0 < budget:
     except Exception as e:
         print(f"seed {seed - 1}: compile: {e}", flush=True)
         continue
-    sc = device.Scanner(db, 0)
     ntiles = (nbytes + 16383) // 16384
     chunk_tiles = max(1024, ntiles // rng.choice([2, 3, 5, 9]) // 1024 * 1024)  # (the engine takes multiples of 1024 tiles)
     if ntiles <= chunk_tiles:
         continue
 
     def run():
+        sc = device.Scanner(db, 0)  # (the engine's knobs are read when a scanner is created)
         st = sc.scan(text.data_ptr(), nbytes, buffer_size=bs, line_base=line_base)
         buf = torch.empty((max(st.n_hits, 1), 2), dtype=torch.int64, device="cuda:0")
         sc.copy_hits_to(buf.data_ptr(), st.n_hits)
@@ -91,7 +91,7 @@ while time.time() - t0 < budget:
         fails += 1
         print(f"MISMATCH seed {seed - 1} kind={kind} n={len(pats)} bytes={nbytes} bs={bs} chunk_tiles={chunk_tiles} launches={many.stream_launches} "
               f"hits {one.n_hits}/{many.n_hits} lines {one.n_lines}/{many.n_lines} info={db.info()} pats={pats[:6]}", flush=True)
-    del text, sc, db
+    del text, db
     if time.time() - last > 30:
         last = time.time()
         print(f"... {cases} cases, {fails} failures, seed {seed}", flush=True)

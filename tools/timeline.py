@@ -7,7 +7,7 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 def short(n):
-    for k in ("hg_stream", "hg_verify", "hg_confirm_fast", "hg_confirm_generic", "hg_tile_reduce", "hg_tile_spine", "hg_tile_apply", "hg_always", "hg_key", "hg_line_key",
+    for k in ("hg_stream", "hg_verify", "hg_confirm_fast", "hg_confirm_literal", "hg_confirm_generic", "hg_confirm_huge", "hg_tile_reduce", "hg_tile_spine", "hg_tile_apply", "hg_always", "hg_key", "hg_line_key",
               "hg_gather", "hg_keep", "radix", "select", "fillBuffer", "copyBuffer", "hg_synth", "onesweep", "histogram", "scan"):
         if k in n:
             return k
