@@ -1000,6 +1000,20 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
   std::vector<uint32_t> next16_of;  // per keyed entry: hg_next16 of the two bytes after the window, 0 if unknown
   const uint32_t fold = db.fold_mask;
   const uint32_t wbytes = db.window_bytes, wmask = db.window_mask;
+  // contenders[v]: the literals (of different patterns or the same) that contain the window value v at some offset
+  std::unordered_map<uint32_t, uint32_t> contenders;
+  for (uint32_t fi = 0; fi < db.nreal_factors; fi++) {
+    const HgFactor &fct = db.factors[fi];
+    std::vector<uint32_t> mine;
+    for (uint32_t o = 0; o + wbytes <= fct.len; o++) {
+      uint32_t v = 0;
+      std::memcpy(&v, fct.lit + o, wbytes);
+      mine.push_back((v | fold) & wmask);
+    }
+    std::sort(mine.begin(), mine.end());
+    mine.erase(std::unique(mine.begin(), mine.end()), mine.end());
+    for (uint32_t v : mine) contenders[v]++;
+  }
   for (uint32_t fi = 0; fi < db.nreal_factors; fi++) {
     const HgFactor &fct = db.factors[fi];
     Lit l{std::string(reinterpret_cast<const char *>(fct.lit), fct.len), std::string(fct.len, '\xFF')};
@@ -1023,10 +1037,15 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
     const uint32_t step = db.dense ? db.dense : 4u;  // the stream pass probes a window every `step` bytes: one window per residue mod step
     for (uint32_t res = 0; res < step; res++) {
       // The stream kernel compares the window in its hot path and the 12-byte neighbourhood [o-4, o+8) in the second level.
-      // With sample statistics: take the offset whose window dword is rarest in the sample.  Without:
-      // the offset whose known bytes are the most selective by a static byte-frequency table.
+      // With sample statistics: take the offset whose window dword is rarest in the sample (exactly: one occurrence in a
+      // 1 MiB sample is 30 000 false candidates in 32 GiB — config 5 went from 42 M to 64 M candidates when small counts
+      // were treated as equal).  Then the offset whose window value no OTHER literal contains anywhere
+      // (`contenders`: a window with one owner goes from the direct table straight to its literal; K%04x-%08x literals all
+      // contain "xxx-" windows that sixteen of them share).  Then the offset whose known bytes are the most selective by a
+      // static byte-frequency table.
       int best = -1;
       long best_cost = 0;
+      uint32_t best_shared = 0;
       int best_sel = -1;
       for (uint32_t o = res; o + wbytes <= fct.len; o += step) {
         uint32_t v = 0;
@@ -1037,11 +1056,17 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
           auto it = stats->c4.find(v);
           cost = it == stats->c4.end() ? 0 : it->second;
         }
+        const uint32_t shared = contenders[v] > 1 ? contenders[v] : 0;
         int sel = 0;
         for (int j = static_cast<int>(o); j < static_cast<int>(o + wbytes); j++) sel += 11 - byte_commonness(static_cast<unsigned char>(l.bytes[j]));
         for (int j = std::max(static_cast<int>(o) - 4, 0); j < std::min<int>(o + 7, fct.len); j++)
           sel += (11 - byte_commonness(static_cast<unsigned char>(l.bytes[j]))) / 4;
-        if (best < 0 || cost < best_cost || (cost == best_cost && sel > best_sel)) { best = static_cast<int>(o); best_cost = cost; best_sel = sel; }
+        if (best < 0 || cost < best_cost || (cost == best_cost && (shared < best_shared || (shared == best_shared && sel > best_sel)))) {
+          best = static_cast<int>(o);
+          best_cost = cost;
+          best_shared = shared;
+          best_sel = sel;
+        }
       }
       if (best < 0) continue;  // cannot happen for len >= HG_FAST_MIN_FACTOR
       uint32_t v = 0;
@@ -1126,7 +1151,7 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
     if (db.windows2.empty()) db.windows2.push_back(HgWindow{0, 0});
   }
 
-  // Direct window table (hg_db.h HgWinEntry): every distinct window value once, with its (literal, offset) when there is only one.
+  // Direct window table (hg_db.h HgWinBucket): every distinct window value once, with its (literal, offset) when there is only one.
   {
     std::vector<std::pair<uint32_t, uint32_t>> vf;  // (value, factor_off)
     for (auto &kw : keyed) vf.push_back({kw.second.value, kw.second.factor_off});
@@ -1136,28 +1161,28 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
     for (size_t i = 0; i < vf.size(); i++) distinct += (i == 0 || vf[i].first != vf[i - 1].first) ? 1 : 0;
     uint32_t nbuckets = 16;
     while (static_cast<size_t>(nbuckets) * HG_WTAB_WAYS < 2 * distinct) nbuckets <<= 1;
-    db.wtab.assign(static_cast<size_t>(nbuckets) * HG_WTAB_WAYS, HgWinEntry{0, 0, 0, 0});
+    HgWinBucket empty;
+    for (uint32_t k = 0; k < HG_WTAB_WAYS; k++) { empty.value[k] = 0; empty.factor_off[k] = HG_WTAB_EMPTY; }
+    db.wtab.assign(nbuckets, empty);
     db.wtab_mask = nbuckets - 1;
-    bool all_single = true;
+    db.shared_windows = 0;
     for (size_t i = 0; i < vf.size();) {
       size_t j = i;
       while (j < vf.size() && vf[j].first == vf[i].first) j++;
-      const HgWinEntry e{vf[i].first, vf[i].second, static_cast<uint32_t>(j - i), 0};
-      all_single = all_single && e.count == 1;
-      for (uint32_t b = hg_wtab_bucket(e.value, db.wtab_mask);; b = (b + 1u) & db.wtab_mask) {
+      const uint32_t payload = j - i == 1 ? vf[i].second : HG_WTAB_SHARED;
+      db.shared_windows += j - i == 1 ? 0 : 1;
+      for (uint32_t b = hg_wtab_bucket(vf[i].first, db.wtab_mask);; b = (b + 1u) & db.wtab_mask) {
         bool placed_here = false;
         for (uint32_t k = 0; k < HG_WTAB_WAYS && !placed_here; k++)
-          if (db.wtab[static_cast<size_t>(b) * HG_WTAB_WAYS + k].count == 0) {
-            db.wtab[static_cast<size_t>(b) * HG_WTAB_WAYS + k] = e;
+          if (db.wtab[b].factor_off[k] == HG_WTAB_EMPTY) {
+            db.wtab[b].value[k] = vf[i].first;
+            db.wtab[b].factor_off[k] = payload;
             placed_here = true;
           }
         if (placed_here) break;
       }
       i = j;
     }
-    bool literal_set = db.nreal_factors > 0;
-    for (uint32_t m = 1; m < HG_CONFIRM_MODES; m++) literal_set = literal_set && db.n_confirm_mode[m] == 0;
-    db.literal_direct = (literal_set && all_single) ? 1u : 0u;
   }
 
   // LDS filter over the distinct window values (single-probe slots below; two-slot cells in wide mode).

@@ -18,10 +18,9 @@ struct HgDb {
   std::vector<uint16_t> disc;         // per hash-C group: discriminator dword (hg_db.h)
   std::vector<uint32_t> bucket_off2;  // (1 << HG_HASH_BITS) + 1 offsets into windows2, indexed by hg_disc_bucket
   std::vector<HgWindow> windows2;     // the same windows ordered by discriminated bucket (GPU verify pass)
-  std::vector<HgWinEntry> wtab;       // direct window table (hg_db.h): (wtab_mask + 1) buckets of HG_WTAB_WAYS entries
+  std::vector<HgWinBucket> wtab;      // direct window table (hg_db.h): wtab_mask + 1 buckets
   uint32_t wtab_mask = 0;
-  uint32_t literal_direct = 0;        // every anchored expression is a SINGLEMATCH literal and every window belongs to ONE (literal, offset):
-                                      // candidates go through hg_literal_kernel (table -> literal -> line) instead of verify + confirm
+  uint32_t shared_windows = 0;        // window values that several literals share (they take the discriminated buckets)
   std::vector<uint32_t> filter;      // 1 << filter_log2 slots holding hash C of the owning window (staged in LDS by the stream kernel)
   uint32_t filter_log2 = HG_FILTER_MIN_LOG2;
   uint32_t filter_wide = 0;          // 1: two 16-bit fingerprints per slot, no neighbour conditions (large pattern sets)

@@ -52,7 +52,7 @@ struct HgDbView {
   const uint16_t *disc;          // GPU verify pass: discriminated buckets (hg_db.h)
   const uint32_t *bucket_off2;
   const HgWindow *windows2;
-  const HgWinEntry *wtab;        // direct window table (hg_db.h)
+  const HgWinBucket *wtab;       // direct window table (hg_db.h)
   uint32_t wtab_mask;
   const uint32_t *slow;
   uint32_t npatterns, nslow, fold_mask;
@@ -148,10 +148,10 @@ HG_HD void hg_verify_window(const HgDbView &db, const uint8_t *text, uint64_t nb
     emit(f.pattern, start, f.len);
   };
   // the direct table first: a value that is not in it belongs to no literal, a value with one owner names it
-  HgWinEntry e;
-  if (!hg_wtab_find(db.wtab, db.wtab_mask, folded, &e)) return;
-  if (e.count == 1) {
-    check(e.factor_off);
+  const uint32_t owner = hg_wtab_find(db.wtab, db.wtab_mask, folded);
+  if (owner == HG_WTAB_EMPTY) return;
+  if (owner != HG_WTAB_SHARED) {
+    check(owner);
     return;
   }
   uint32_t j0, j1;

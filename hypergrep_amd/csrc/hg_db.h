@@ -136,26 +136,25 @@ HG_HD uint32_t hg_factor_mask_dword(uint32_t casebits, uint32_t len, uint32_t j)
   return valid >= 4u ? m : (m & ((1u << (8u * valid)) - 1u));
 }
 
-// Direct window table: the folded value of a literal window -> the (literal, offset) it belongs to, in ONE 64-byte fetch
-// (a bucket of four entries; open addressing over buckets, filled front to back and never more than half full).  count == 1:
-// factor_off names the only (literal, offset) with this window; count > 1: several literals share the window, the
-// discriminated buckets (disc / bucket_off2 / windows2 below) name them; count == 0: empty.  A window value that is not in
-// the table belongs to no literal: the stream filter's false positives end here.
-struct HgWinEntry {
-  uint32_t value, factor_off, count, reserved;
+// Direct window table: the folded value of a literal window -> the (literal, offset) it belongs to.  A bucket = four values
+// (one 16-byte fetch) + their four payloads, 32 bytes; open addressing over buckets, filled front to back, never more than
+// half full over all.  Payload: factor_off of the only (literal, offset) with this window; HG_WTAB_SHARED: several literals
+// share the window, the discriminated buckets (disc / bucket_off2 / windows2 below) name them; HG_WTAB_EMPTY: no entry.  A
+// window value that is not in the table belongs to no literal: the stream filter's false positives end here.
+struct HgWinBucket {
+  uint32_t value[4];
+  uint32_t factor_off[4];
 };
-static_assert(sizeof(HgWinEntry) == 16, "HgWinEntry layout");
-constexpr uint32_t HG_WTAB_WAYS = 4;
+static_assert(sizeof(HgWinBucket) == 32, "HgWinBucket layout");
+constexpr uint32_t HG_WTAB_WAYS = 4, HG_WTAB_EMPTY = 0xFFFFFFFFu, HG_WTAB_SHARED = 0xFFFFFFFEu;
 HG_HD uint32_t hg_wtab_bucket(uint32_t folded, uint32_t bucket_mask) { return ((folded * 0x9E3779B1u) >> 9) & bucket_mask; }
-HG_HD bool hg_wtab_find(const HgWinEntry *tab, uint32_t bucket_mask, uint32_t folded, HgWinEntry *out) {
+// Returns HG_WTAB_EMPTY (not in the table), HG_WTAB_SHARED, or the factor_off of the window's only owner.
+HG_HD uint32_t hg_wtab_find(const HgWinBucket *tab, uint32_t bucket_mask, uint32_t folded) {
   for (uint32_t b = hg_wtab_bucket(folded, bucket_mask);; b = (b + 1u) & bucket_mask) {
-    const HgWinEntry *e = tab + static_cast<size_t>(b) * HG_WTAB_WAYS;
+    const HgWinBucket &e = tab[b];
     for (uint32_t k = 0; k < HG_WTAB_WAYS; k++) {
-      if (e[k].count == 0) return false;
-      if (e[k].value == folded) {
-        *out = e[k];
-        return true;
-      }
+      if (e.factor_off[k] == HG_WTAB_EMPTY) return HG_WTAB_EMPTY;
+      if (e.value[k] == folded) return e.factor_off[k];
     }
   }
 }

@@ -145,7 +145,6 @@ struct HgEngineKnobs {
   uint64_t hit_limit = 0;          // HG_HIT_LIMIT (0: default 2^28)
   uint64_t cand_limit = 0;         // HG_CAND_LIMIT (0: default 2^30)
   bool verbose = false;            // HG_VERBOSE
-  bool no_literal_direct = false;  // HG_NO_LITERAL_DIRECT: literal sets through verify + confirm like any other set (A/B)
   static HgEngineKnobs from_env();
 };
 

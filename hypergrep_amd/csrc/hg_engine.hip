@@ -41,7 +41,7 @@ __global__ void hg_fin_sort_big_kernel(const HgHit *hits, uint32_t *idx, const u
 template <uint32_t THREADS>
 __global__ void hg_fin_scan_kernel(uint32_t *kept_count, uint32_t b_lo, uint32_t b_hi, uint32_t *total, const uint32_t *fill, uint32_t cap, uint32_t *part, uint32_t epoch);
 __global__ void hg_confirm_literal_kernel(HgConfirmArgs a);
-__global__ void hg_literal_kernel(HgConfirmArgs a);
+__global__ void hg_verify_lean_kernel(HgConfirmArgs a);
 __global__ void hg_fin_gather_kernel(const HgHit *hits, const HgHitAux *aux, const uint32_t *idx, const uint32_t *kept_base, const uint32_t *total, uint32_t b_lo,
                                      uint32_t b_hi, uint32_t cap, HgHit *oh, HgHitAux *oa);
 __global__ void hg_key_kernel(const HgHit *hits, const HgHitAux *aux, const HgPattern *patterns, uint32_t n, uint64_t *key, uint32_t *idx);
@@ -99,7 +99,7 @@ HgEngineKnobs HgEngineKnobs::from_env() {
   k.hit_limit = num("HG_HIT_LIMIT", 0);
   k.cand_limit = num("HG_CAND_LIMIT", 0);
   k.verbose = std::getenv("HG_VERBOSE") != nullptr;
-  k.no_literal_direct = std::getenv("HG_NO_LITERAL_DIRECT") != nullptr;
+
   return k;
 }
 
@@ -159,7 +159,7 @@ int HgScanner::create(std::shared_ptr<const HgDb> db, int device, HgScanner **ou
   s->view_.disc = static_cast<const uint16_t *>(s->d_disc_);
   s->view_.bucket_off2 = static_cast<const uint32_t *>(s->d_bucket2_);
   s->view_.windows2 = static_cast<const HgWindow *>(s->d_windows2_);
-  s->view_.wtab = static_cast<const HgWinEntry *>(s->d_wtab_);
+  s->view_.wtab = static_cast<const HgWinBucket *>(s->d_wtab_);
   s->view_.wtab_mask = db->wtab_mask;
   s->view_.slow = static_cast<const uint32_t *>(s->d_slow_);
   s->view_.npatterns = static_cast<uint32_t>(db->patterns.size());
@@ -587,13 +587,11 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
             ca.list_spread[m] = std::min<uint32_t>(HG_DEFER_SHARDS, std::max<uint32_t>(1, HG_DEFER_SHARDS / std::max<uint32_t>(1, db_->n_confirm_mode[m])) * defer_spread_boost_);
           }
           if (c > 0) HG_TRY(hipMemsetAsync(d_defer_count_, 0, HG_CONFIRM_MODES * HG_DEFER_SHARDS * 4, side), "memset deferred counts");  // (chunk 0: hg_reset_kernel)
-          // (a set of literals whose windows each have one owner: window -> hit in one kernel, no lists: hg_literal_kernel)
-          const bool direct = db_->literal_direct && !knobs_.no_literal_direct;
-          if (direct) hipLaunchKernelGGL(hg_literal_kernel, dim3(verify_blocks), dim3(256), 0, side, ca);
-          else hipLaunchKernelGGL(hg_verify_kernel, dim3(verify_blocks), dim3(256), 0, side, ca);
+          // (sets without automaton modes 1 / 2: the verify variant without the LDS staging area)
+          if (ca.mode_present[1] || ca.mode_present[2]) hipLaunchKernelGGL(hg_verify_kernel, dim3(verify_blocks), dim3(256), 0, side, ca);
+          else hipLaunchKernelGGL(hg_verify_lean_kernel, dim3(verify_blocks), dim3(256), 0, side, ca);
           const bool literal_only_set = ca.mode_present[0] && !ca.mode_present[1] && !ca.mode_present[2];
-          if (direct) {
-          } else if (literal_only_set) hipLaunchKernelGGL(hg_confirm_literal_kernel, dim3(mode_blocks), dim3(256), 0, side, ca);  // (blocks of 256: as many lanes per CU as before)
+          if (literal_only_set) hipLaunchKernelGGL(hg_confirm_literal_kernel, dim3(mode_blocks), dim3(256), 0, side, ca);  // (blocks of 256: as many lanes per CU as before)
           else if (fast_modes) hipLaunchKernelGGL(hg_confirm_fast_kernel, dim3(mode_blocks * fast_modes), dim3(HG_CONFIRM_THREADS), 0, side, ca, mode_blocks);
           if (db_->n_confirm_mode[3]) hipLaunchKernelGGL(hg_confirm_generic_kernel, dim3(mode_blocks), dim3(256), 0, side, ca);
           if (huge_blocks && ((mode_mask >> 4) & 1u)) {

@@ -869,17 +869,16 @@ __device__ __forceinline__ void verify_stage_flush(const HgConfirmArgs &a, Verif
   __syncthreads();
 }
 
-// Direct window table lookup (hg_db.h HgWinEntry), a bucket of four entries with ONE cache-line fetch.  Returns the entry's
-// count (0: the value belongs to no literal) and its factor_off.
-__device__ __forceinline__ uint32_t wtab_lookup(const HgWinEntry *tab, uint32_t bucket_mask, uint32_t folded, uint32_t *factor_off) {
+// Direct window table lookup (hg_db.h HgWinBucket): the bucket's four values in one 16-byte fetch, then the payload of the one
+// that matched (the same 32-byte sector).  Returns the owner's factor_off, HG_WTAB_SHARED or HG_WTAB_EMPTY.
+__device__ __forceinline__ uint32_t wtab_lookup(const HgWinBucket *tab, uint32_t bucket_mask, uint32_t folded) {
   for (uint32_t b = hg_wtab_bucket(folded, bucket_mask);; b = (b + 1u) & bucket_mask) {
-    const uint4 *e = reinterpret_cast<const uint4 *>(tab + static_cast<size_t>(b) * HG_WTAB_WAYS);
-    const uint4 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];  // {value, factor_off, count, -}
-    if (e0.z && e0.x == folded) { *factor_off = e0.y; return e0.z; }
-    if (e1.z && e1.x == folded) { *factor_off = e1.y; return e1.z; }
-    if (e2.z && e2.x == folded) { *factor_off = e2.y; return e2.z; }
-    if (e3.z && e3.x == folded) { *factor_off = e3.y; return e3.z; }
-    if (!e3.z) return 0;  // the bucket has room left: the value would be here (buckets fill front to back)
+    const uint4 v = *reinterpret_cast<const uint4 *>(tab[b].value);
+    // (an empty slot holds value 0 and payload EMPTY: a match on an empty slot's value returns EMPTY, which is right)
+    const uint32_t k = v.x == folded ? 0u : (v.y == folded ? 1u : (v.z == folded ? 2u : 3u));
+    const uint32_t payload = tab[b].factor_off[k];
+    if (k < 3u || v.w == folded) return payload;  // found (or the empty slot that holds value 0)
+    if (payload == HG_WTAB_EMPTY) return HG_WTAB_EMPTY;  // not found and the bucket has room left: the value would be here
   }
 }
 // Does the literal of `f` (len bytes, HgFactor) occur at text[fs, fs + len)?  The record is one cache line: the literal as
@@ -905,45 +904,16 @@ __device__ __forceinline__ bool literal_occurs(const HgFactor *f, uint32_t len, 
   return diff == 0;
 }
 
-// Pattern sets of SINGLEMATCH literals whose windows each belong to ONE (literal, offset) (HgDb::literal_direct: config 5's 4096
-// literals, a single keyword): a candidate goes from window to hit in one lane's straight line — table bucket -> literal record
-// + text -> line geometry -> report — instead of through the verify pass, a verified-occurrence list and a confirm pass.
-// The line's bytes around the occurrence are fetched once (the walk's first chunk is the line the compare just read).
-__global__ __launch_bounds__(256) void hg_literal_kernel(HgConfirmArgs a) {
-  __shared__ uint32_t s_n, s_base;
-  if (threadIdx.x == 0) s_n = 0;
-  __syncthreads();
-  const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
-  const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n};
-  const uint32_t seg = blockIdx.x / HG_CONFIRM_SPLIT, sub = blockIdx.x % HG_CONFIRM_SPLIT;
-  const HgCand *cseg = a.cands + static_cast<uint64_t>(seg) * a.cand_seg_cap;
-  uint32_t n = a.seg_count[seg];
-  if (n > a.cand_seg_cap) n = a.cand_seg_cap;
-  const uint32_t fold = a.db.fold_mask;
-  const uint64_t readable = (a.nbytes + 15) & ~15ull;
-  for (uint32_t i = sub * 256u + threadIdx.x; i < n; i += HG_CONFIRM_SPLIT * 256u) {
-    const HgCand c = cseg[i];
-    const uint32_t folded = (c.word | fold) & a.db.window_mask;
-    uint32_t fo = 0;
-    if (!wtab_lookup(a.db.wtab, a.db.wtab_mask, folded, &fo)) continue;
-    const uint32_t off = fo & 0xffu;
-    const HgFactor *f = &a.db.factors[fo >> 8];
-    const uint4 hdr = *reinterpret_cast<const uint4 *>(f);  // pattern, len, mode, mode_rank
-    const uint32_t len = hdr.y;
-    if (c.pos < off || c.pos - off + len > a.nbytes) continue;
-    const uint64_t fs = c.pos - off;
-    if (!literal_occurs(f, len, a.text, fs, readable, fold != 0)) continue;
-    const uint32_t id = f->id, pattern = hdr.x;
-    hgdev::confirm_literal(a.text, a.nbytes, a.sums, a.bases, a.bs1, c.pos, c.rank, fs, len,
-                           [&](uint64_t line_no, uint32_t to, uint64_t start, uint32_t llen) { sink.push(a, line_no, id, to, start, llen, pattern, true); });
+// STAGED: the set has automaton expressions of confirm modes 1 / 2, whose occurrences are staged in LDS and filed by pattern.
+// A set without them (literals, config 5) runs the variant without the 14 KiB staging area: beside two stream workgroups
+// with 64 KiB filters a CU has 16 KiB of LDS left, and the staging area held the pass to ONE block per CU.
+template <bool STAGED>
+__device__ __forceinline__ void verify_body(const HgConfirmArgs &a, VerifyStage *stage) {
+  VerifyStage &s_stage = *stage;
+  if (STAGED) {
+    if (threadIdx.x == 0) s_stage.n = 0;
+    __syncthreads();
   }
-  flush_hits(a, &s_n, &s_base);
-}
-
-__global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
-  __shared__ VerifyStage s_stage;
-  if (threadIdx.x == 0) s_stage.n = 0;
-  __syncthreads();
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 #ifdef HG_PROFILE_CONFIRM
   const uint64_t pf_t0 = wall_clock64();
@@ -957,10 +927,12 @@ __global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
   const uint32_t fold = a.db.fold_mask;
   const uint64_t readable = (a.nbytes + 15) & ~15ull;  // the text buffer can be read up to here
   for (uint32_t base0 = sub * 256u; base0 < n; base0 += HG_CONFIRM_SPLIT * 256u) {  // block-uniform: the staging flush is a block affair
-    __syncthreads();  // every wave has finished the previous round: the fill level is final ...
-    const uint32_t staged = s_stage.n;
-    __syncthreads();  // ... and has been read by all before anyone stages again
-    if (staged >= VERIFY_STAGE_CAP / 2) verify_stage_flush(a, s_stage);
+    if (STAGED) {
+      __syncthreads();  // every wave has finished the previous round: the fill level is final ...
+      const uint32_t staged = s_stage.n;
+      __syncthreads();  // ... and has been read by all before anyone stages again
+      if (staged >= VERIFY_STAGE_CAP / 2) verify_stage_flush(a, s_stage);
+    }
     const uint32_t base = base0 + wave * 64u;
     const uint32_t i = base + lane;
     HgCand c{0, 0, 0};
@@ -971,9 +943,9 @@ __global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
       folded = (c.word | fold) & a.db.window_mask;
       // the direct table: a value it does not hold belongs to no literal (the filter's false positives end here, one fetch
       // each); a value with one owner names it; only windows that several literals share go through the discriminated buckets
-      const uint32_t owners = wtab_lookup(a.db.wtab, a.db.wtab_mask, folded, &direct_fo);
-      direct = owners == 1;
-      shared = owners > 1;
+      direct_fo = wtab_lookup(a.db.wtab, a.db.wtab_mask, folded);
+      shared = direct_fo == HG_WTAB_SHARED;
+      direct = !shared && direct_fo != HG_WTAB_EMPTY;
       if (direct) cnt = 1;
     }
     if (shared) {
@@ -1054,7 +1026,7 @@ __global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
       for (uint32_t m = 0; m < HG_CONFIRM_MODES; m++) {
         const uint64_t mm = __builtin_amdgcn_ballot_w64(ok && mode == m);
         if (!mm) continue;
-        if (m == 1 || m == 2) {  // staged, keyed by pattern (a pattern set with few such patterns spreads each over several lists)
+        if (STAGED && (m == 1 || m == 2)) {  // staged, keyed by pattern (a pattern set with few such patterns spreads each over several lists)
           uint32_t at0 = 0;
           if (lane == 0) at0 = atomicAdd(&s_stage.n, static_cast<uint32_t>(__popcll(mm)));
           at0 = __builtin_amdgcn_readfirstlane(at0);
@@ -1085,11 +1057,18 @@ __global__ __launch_bounds__(256) void hg_verify_kernel(HgConfirmArgs a) {
       }
     }
   }
-  verify_stage_flush(a, s_stage);
+  if (STAGED) verify_stage_flush(a, s_stage);
 #ifdef HG_PROFILE_CONFIRM
   if (lane == 0) a.tmp_hits[(6u << 20) + 65536u + blockIdx.x * 4u + wave] = HgHit{pf_t0, static_cast<uint32_t>(wall_clock64() - pf_t0), pf_rounds | (pf_pairs << 8)};
 #endif
 }
+// (the register budgets: beside two stream workgroups — 4 waves of 80 VGPRs per SIMD — a SIMD has 192 VGPRs left; at 64 the
+// pass keeps three waves per SIMD there, at 80 two.  The pass lives on resident waves: every candidate is a chain of fetches.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void hg_verify_kernel(HgConfirmArgs a) {
+  __shared__ VerifyStage s_stage;
+  verify_body<true>(a, &s_stage);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void hg_verify_lean_kernel(HgConfirmArgs a) { verify_body<false>(a, nullptr); }
 
 // Confirm passes over the lists of verified occurrences, one routine per confirm mode so that the lanes of a wave do the
 // same work:
@@ -1292,6 +1271,8 @@ __global__ __launch_bounds__(256) void hg_confirm_generic_kernel(HgConfirmArgs a
 // Pattern sets whose anchored expressions are ALL literal-only (config 5's 4096 literals, a single keyword): the routine on its
 // own, at a third of the registers of the three-routine kernel — the pass is a chain of dependent loads per occurrence, and
 // resident waves are what hides them.
+// (its natural register count: capped at 64 for a third wave per SIMD beside the stream pass it spills 164 bytes per lane and takes
+// 2.35 ms per 8 GiB of config 5 instead of 1.3)
 __global__ __launch_bounds__(256) void hg_confirm_literal_kernel(HgConfirmArgs a) { confirm_body<0>(a, blockIdx.x, gridDim.x); }
 
 // Scalar always-on pass over the entries [first, last) of the always-on list (patterns of more than two state words).

@@ -62,7 +62,7 @@ static HgDbView view_of(HgDb *db);
 //  (1) passes the first level at its own slot, (2) passes the second level when the literal's own bytes surround it,
 //  (3) is found by the verify pass's discriminated bucket lookup when the literal itself is the text.
 // Returns the number of violations; out[0] = filter log2, out[1] = wide, out[2] = slots holding more than two values.
-uint32_t hgsim_selfcheck(void *h, uint32_t *out) {
+uint32_t hgsim_selfcheck(void *h, uint32_t *out) {  // out[5]
   HgDb *db = static_cast<HgDb *>(h);
   const HgDbView v = view_of(db);
   uint32_t bad = 0, many = 0;
@@ -107,17 +107,19 @@ uint32_t hgsim_selfcheck(void *h, uint32_t *out) {
     for (uint32_t j = j0; j < j1; j++) found = found || (db->windows2[j].value == w.value && db->windows2[j].factor_off == w.factor_off);
     if (!found) bad++;
     // (4) the direct table holds the window's value; with one owner it names exactly this (literal, offset)
-    HgWinEntry e;
-    if (!hg_wtab_find(db->wtab.data(), db->wtab_mask, w.value, &e) || (e.count == 1 && e.factor_off != w.factor_off)) bad++;
+    const uint32_t owner = hg_wtab_find(db->wtab.data(), db->wtab_mask, w.value);
+    if (owner == HG_WTAB_EMPTY || (owner != HG_WTAB_SHARED && owner != w.factor_off)) bad++;
   }
   if (out) { out[0] = db->filter_log2; out[1] = db->filter_wide; out[2] = many; out[3] = db->dense; }
   // the table's buckets fill front to back and are never more than half full over all
   size_t used = 0;
-  for (size_t i = 0; i < db->wtab.size(); i++) {
-    used += db->wtab[i].count ? 1 : 0;
-    if (i % HG_WTAB_WAYS && db->wtab[i].count && !db->wtab[i - 1].count) bad++;
-  }
-  if (used * 2 > db->wtab.size() || (db->wtab.size() / HG_WTAB_WAYS) != static_cast<size_t>(db->wtab_mask) + 1) bad++;
+  for (const HgWinBucket &b : db->wtab)
+    for (uint32_t k = 0; k < HG_WTAB_WAYS; k++) {
+      used += b.factor_off[k] != HG_WTAB_EMPTY ? 1 : 0;
+      if (k && b.factor_off[k] != HG_WTAB_EMPTY && b.factor_off[k - 1] == HG_WTAB_EMPTY) bad++;
+    }
+  if (used * 2 > db->wtab.size() * HG_WTAB_WAYS || db->wtab.size() != static_cast<size_t>(db->wtab_mask) + 1) bad++;
+  if (out) out[4] = db->shared_windows;
   return bad;
 }
 uint32_t hgsim_pattern_tier(void *h, uint32_t i) { return static_cast<HgDb *>(h)->patterns[i].tier; }
