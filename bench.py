@@ -228,6 +228,8 @@ def main() -> None:
 
     if world > 1:
         prime()
+        step()  # untimed, whatever --warmup says: the first gather sets up the point-to-point channels of the backend
+        drain()
     for _ in range(args.warmup):
         step()
     drain()

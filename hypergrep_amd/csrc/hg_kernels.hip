@@ -1322,8 +1322,16 @@ struct AlwaysOnCtx {
   uint32_t list_cap;
   hgdev::lds_u32 *list_count;  // LDS counter of the block
 };
+// (called under divergent control flow: the lanes that are here together share ONE atomic on the block's counter — a hit-heavy
+// set, a match on most lines, used to send 64 atomics per wave step to one LDS address)
 __device__ __forceinline__ void always_on_note(const AlwaysOnCtx &cx, uint32_t pi, uint64_t end, uint32_t rank_at_last) {
-  const uint32_t slot = __hip_atomic_fetch_add(cx.list_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const uint64_t here = __builtin_amdgcn_ballot_w64(true);
+  const uint32_t leader = static_cast<uint32_t>(__builtin_ctzll(here));
+  const uint32_t mine = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(here >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(here), 0u));
+  uint32_t base = 0;
+  if (mine == 0) base = __hip_atomic_fetch_add(cx.list_count, static_cast<uint32_t>(__popcll(here)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  base = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(base), static_cast<int>(leader)));
+  const uint32_t slot = base + mine;
   if (slot < cx.list_cap) cx.list[slot] = HgDeferred{end, pi, rank_at_last};
 }
 
