@@ -43,7 +43,7 @@ enum { HG_CNT_CANDS = 0, HG_CNT_HITS = 1, HG_CNT_CAND_NEED = 2, HG_CNT_HIT_NEED 
 constexpr uint32_t HG_STREAM_GRAB = 2 * HG_STREAM_WG_WAVES_DEFAULT;  // tiles per draw of a stream workgroup: two per wave
 
 // Bucketed finalize (hg_fin_*): buckets of the final ordering and the largest bucket one wave sorts in LDS.
-constexpr uint32_t HG_FIN_MAX_BUCKETS = 1u << 20;
+constexpr uint32_t HG_FIN_MAX_BUCKETS = 1u << 22;  // (a pass holds at most 2^28 reports: 64 per bucket then, what one wave orders)
 constexpr uint32_t HG_FIN_BUCKET_CAP = 4096;
 constexpr uint32_t HG_FIN_MEDIUM_CAP = 512;  // size class of hg_fin_sort_big_kernel that needs little LDS
 
@@ -235,6 +235,7 @@ class HgScanner {
   // fin_fallback_: a bucket outgrew what one block sorts, the compact array + library sort is used from then on
   uint32_t *d_fin_fill_ = nullptr, *d_fin_kept_ = nullptr, *d_fin_total_ = nullptr, *d_fin_big_ = nullptr;
   bool fin_fallback_ = false;
+  uint32_t fin_alloc_ = 0;  // buckets the arrays above hold (they grow with the bucket count a pass asks for)
   uint32_t fin_epoch_ = 0;  // hg_fin_scan_kernel: a fresh value per launch marks the blocks' partial sums as this launch's
   uint64_t fin_expect_hits_ = 0;  // raw hits of the last pass: the next one picks its bucket count for ~24 records a bucket
   void *d_huge_claim_ = nullptr;      // huge automata: (piece start, expression) pairs already run (hg_confirm_huge_kernel), 8-byte slots

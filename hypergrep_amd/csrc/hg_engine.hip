@@ -34,7 +34,7 @@ __global__ void hg_block_small_kernel(HgDbView db, const uint8_t *h_text, uint32
 __global__ void hg_reset_kernel(uint32_t *state, uint32_t state_words, HgTileBase *final_state, uint64_t carry_start, uint64_t first_piece, uint32_t *fill, uint32_t nb, uint32_t *defer_count,
                                 uint32_t ndefer);
 __global__ void hg_fin_sort_small_kernel(const HgHit *hits, uint32_t *idx, const uint32_t *fill, uint32_t b_lo, uint32_t b_hi, uint32_t cap, uint32_t id_bits,
-                                         uint32_t to_bits, uint32_t *kept_count, uint32_t *big_list, uint32_t *big_count);
+                                         uint32_t to_bits, uint32_t *kept_count, uint32_t *big_list, uint32_t *big_count, uint32_t big_stride);
 template <uint32_t LCAP, bool IN_LDS>
 __global__ void hg_fin_sort_big_kernel(const HgHit *hits, uint32_t *idx, const uint32_t *fill, const uint32_t *big_list, const uint32_t *big_count, uint32_t cap,
                                        uint32_t id_bits, uint32_t to_bits, uint32_t *kept_count, uint32_t *overflow, uint64_t *scratch_key, uint32_t *scratch_idx);
@@ -307,12 +307,12 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
 #define HG_TRY(call, what) \
   if (fail((call), what)) return HG_ERR_HIP;
   HG_TRY(hipEventRecord(ev_[0], stream), "event");
-  // Bucketed emission + finalize (hg_fin_*): buckets of 2^fin_shift text bytes (4 KiB at least) by line start, at most
+  // Bucketed emission + finalize (hg_fin_*): buckets of 2^fin_shift text bytes (1 KiB at least) by line start, at most
   // HG_FIN_MAX_BUCKETS of them, each a region of fin_cap records of the hit arrays.
   const uint32_t id_bits = bits_for(static_cast<uint64_t>(db_->max_id) + 1), to_bits = bits_for(bs1 + 1);
   // As many buckets as give ~30-50 records each (one wave orders up to 64 in registers; larger buckets go through LDS): from
   // the last pass's hits, else one hit per 8 KiB of text as a first guess.
-  uint32_t fin_shift = 12, fin_nb = 1;
+  uint32_t fin_shift = 10, fin_nb = 1;  // (1 KiB buckets at least: a text with a report on every line has ~10 per KiB)
   if (own_len) {
     const uint64_t expect = std::max<uint64_t>(fin_expect_hits_, own_len >> 13);
     uint64_t want_nb = 1;
@@ -324,11 +324,19 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
   const uint32_t fin_cap = hit_cap_ / fin_nb;
   // (sort key of a bucket: line start inside the bucket | id | to | single; the raw records carry that start in the top
   // 24 bits of the line number, so line numbers must stay below 2^40)
-  if (ntiles && !d_fin_fill_ && !fin_fallback_) {
-    HG_TRY(hgmem::dev_alloc(&d_fin_fill_, HG_FIN_MAX_BUCKETS * 4, "d_fin_fill_"), "alloc finalize buckets");
-    HG_TRY(hgmem::dev_alloc(&d_fin_kept_, HG_FIN_MAX_BUCKETS * 4, "d_fin_kept_"), "alloc finalize buckets");
-    HG_TRY(hgmem::dev_alloc(&d_fin_big_, (2 * HG_FIN_MAX_BUCKETS + 3 * 128) * 4, "d_fin_big_"), "alloc finalize buckets");  // (two work lists + the scan's partial sums)
-    HG_TRY(hipMemsetAsync(d_fin_big_ + 2 * HG_FIN_MAX_BUCKETS, 0, 3 * 128 * 4, stream), "clear scan flags");
+  if (ntiles && !fin_fallback_ && fin_nb > fin_alloc_) {  // (64 K buckets at least, then by powers of two up to HG_FIN_MAX_BUCKETS)
+    uint32_t want = 1u << 16;
+    while (want < fin_nb) want <<= 1;
+    hgmem::dev_free(d_fin_fill_, "d_fin_fill_");
+    hgmem::dev_free(d_fin_kept_, "d_fin_kept_");
+    hgmem::dev_free(d_fin_big_, "d_fin_big_");
+    d_fin_fill_ = d_fin_kept_ = d_fin_big_ = nullptr;
+    fin_alloc_ = 0;
+    HG_TRY(hgmem::dev_alloc(&d_fin_fill_, static_cast<size_t>(want) * 4, "d_fin_fill_"), "alloc finalize buckets");
+    HG_TRY(hgmem::dev_alloc(&d_fin_kept_, static_cast<size_t>(want) * 4, "d_fin_kept_"), "alloc finalize buckets");
+    HG_TRY(hgmem::dev_alloc(&d_fin_big_, (2 * static_cast<size_t>(want) + 3 * 128) * 4, "d_fin_big_"), "alloc finalize buckets");  // (two work lists + the scan's partial sums)
+    HG_TRY(hipMemsetAsync(d_fin_big_ + 2 * static_cast<size_t>(want), 0, 3 * 128 * 4, stream), "clear scan flags");
+    fin_alloc_ = want;
   }
   const bool bucketed = ntiles && d_fin_fill_ && fin_cap && fin_shift <= 64 - HG_HIT_REL_SHIFT && fin_shift + id_bits + to_bits + 1 <= 64 &&
                         bits_for(line_base + nbytes + 1) <= HG_HIT_REL_SHIFT && !fin_fallback_ && !knobs_.no_bucket_finalize;
@@ -434,17 +442,17 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       const uint32_t nbk = hi - lo, cu = static_cast<uint32_t>(num_cus_);
       HG_TRY(hipMemsetAsync(d_fin_total_ + 2, 0, 8, s), "memset work list");  // (larger buckets of this range: two size classes)
       hipLaunchKernelGGL(hg_fin_sort_small_kernel, dim3(std::min<uint32_t>((nbk + 3) / 4, cu * 8)), dim3(256), 0, s, d_hits_raw_, d_perm_a_, d_fin_fill_, lo, hi, fin_cap, id_bits, to_bits,
-                         d_fin_kept_, d_fin_big_, d_fin_total_ + 2);
+                         d_fin_kept_, d_fin_big_, d_fin_total_ + 2, fin_alloc_);
       hipLaunchKernelGGL((hg_fin_sort_big_kernel<HG_FIN_MEDIUM_CAP, true>), dim3(std::min<uint32_t>(nbk, cu * 4)), dim3(256), 0, s, d_hits_raw_, d_perm_a_, d_fin_fill_, d_fin_big_, d_fin_total_ + 2,
                          fin_cap, id_bits, to_bits, d_fin_kept_, d_selected_ + 1, static_cast<uint64_t *>(nullptr), static_cast<uint32_t *>(nullptr));
       // (scratch of the large class: the key / permutation arrays of the library sort, idle while the scanner emits into buckets)
       const uint32_t big_blocks = std::min<uint32_t>(std::min<uint32_t>(nbk, 64u), hit_cap_ / HG_FIN_BUCKET_CAP);
       if (big_blocks)
-        hipLaunchKernelGGL((hg_fin_sort_big_kernel<HG_FIN_BUCKET_CAP, false>), dim3(big_blocks), dim3(256), 0, s, d_hits_raw_, d_perm_a_, d_fin_fill_, d_fin_big_ + HG_FIN_MAX_BUCKETS,
+        hipLaunchKernelGGL((hg_fin_sort_big_kernel<HG_FIN_BUCKET_CAP, false>), dim3(big_blocks), dim3(256), 0, s, d_hits_raw_, d_perm_a_, d_fin_fill_, d_fin_big_ + fin_alloc_,
                            d_fin_total_ + 3, fin_cap, id_bits, to_bits, d_fin_kept_, d_selected_ + 1, d_key_a_, d_perm_b_);
       // (a block per 8192 buckets, 128 at most: their partial sums live behind the two work lists)
       const uint32_t scan_blocks = std::max<uint32_t>(1, std::min<uint32_t>(128, (nbk + 8191) / 8192));
-      uint32_t *part = d_fin_big_ + 2 * HG_FIN_MAX_BUCKETS;
+      uint32_t *part = d_fin_big_ + 2 * static_cast<size_t>(fin_alloc_);
       const uint32_t epoch = ++fin_epoch_ ? fin_epoch_ : ++fin_epoch_;  // (never 0: the flags start out zeroed)
       if (beside_stream) hipLaunchKernelGGL(hg_fin_scan_kernel<512u>, dim3(scan_blocks), dim3(512), 0, s, d_fin_kept_, lo, hi, d_fin_total_, d_fin_fill_, fin_cap, part, epoch);
       else hipLaunchKernelGGL(hg_fin_scan_kernel<1024u>, dim3(scan_blocks), dim3(1024), 0, s, d_fin_kept_, lo, hi, d_fin_total_, d_fin_fill_, fin_cap, part, epoch);

@@ -1322,16 +1322,11 @@ struct AlwaysOnCtx {
   uint32_t list_cap;
   hgdev::lds_u32 *list_count;  // LDS counter of the block
 };
-// (called under divergent control flow: the lanes that are here together share ONE atomic on the block's counter — a hit-heavy
-// set, a match on most lines, used to send 64 atomics per wave step to one LDS address)
+// (one LDS atomic per noted match.  Round 3 tried one atomic per wave step — ballot of the lanes that are at the call together,
+// mbcnt, readlane: no difference, 142.6 against 143.0 GiB/s on the hit-heavy set [0-9]+\.[0-9]+; what bounded that set was the
+// finalize: 76 reports per bucket with the bucket count capped at 2^20, all of them sorted by the block-per-bucket kernel)
 __device__ __forceinline__ void always_on_note(const AlwaysOnCtx &cx, uint32_t pi, uint64_t end, uint32_t rank_at_last) {
-  const uint64_t here = __builtin_amdgcn_ballot_w64(true);
-  const uint32_t leader = static_cast<uint32_t>(__builtin_ctzll(here));
-  const uint32_t mine = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(here >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(here), 0u));
-  uint32_t base = 0;
-  if (mine == 0) base = __hip_atomic_fetch_add(cx.list_count, static_cast<uint32_t>(__popcll(here)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  base = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(base), static_cast<int>(leader)));
-  const uint32_t slot = base + mine;
+  const uint32_t slot = __hip_atomic_fetch_add(cx.list_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   if (slot < cx.list_cap) cx.list[slot] = HgDeferred{end, pi, rank_at_last};
 }
 
@@ -1947,7 +1942,8 @@ __device__ __forceinline__ uint64_t fin_key(const HgHit &h, uint32_t id_bits, ui
 // SINGLEMATCH report (bit 0) is kept only if it is the first one of its (line, id) = key >> group_shift.
 // Buckets of up to 64 reports (nearly all of them): one wave, one report per lane, the rules as bit operations on ballots.
 __global__ __launch_bounds__(256) void hg_fin_sort_small_kernel(const HgHit *hits, uint32_t *idx, const uint32_t *fill, uint32_t b_lo, uint32_t b_hi, uint32_t cap,
-                                                                uint32_t id_bits, uint32_t to_bits, uint32_t *kept_count, uint32_t *big_list, uint32_t *big_count) {
+                                                                uint32_t id_bits, uint32_t to_bits, uint32_t *kept_count, uint32_t *big_list, uint32_t *big_count,
+                                                                uint32_t big_stride) {
   const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, waves = (gridDim.x * blockDim.x) >> 6;
   const uint32_t group_shift = to_bits + 1;
   // A bucket's fill level and its first 64 records are loaded TOGETHER (lanes past the fill level read records of the same
@@ -1971,7 +1967,7 @@ __global__ __launch_bounds__(256) void hg_fin_sort_small_kernel(const HgHit *hit
     if (n > 64) {  // hg_fin_sort_big_kernel's: noted in the work list of its size class (up to HG_FIN_MEDIUM_CAP records / more)
       if (lane == 0) {
         const uint32_t cls = n <= HG_FIN_MEDIUM_CAP ? 0u : 1u;
-        big_list[cls * HG_FIN_MAX_BUCKETS + atomicAdd(big_count + cls, 1u)] = b;
+        big_list[cls * big_stride + atomicAdd(big_count + cls, 1u)] = b;  // (big_stride: the bucket arrays' allocated length)
       }
       continue;
     }

@@ -1,7 +1,11 @@
 """Throughput of patterns without a long required literal (always-on tier) next to a prefiltered one; GPU box only."""
 import sys, time
 sys.path.insert(0, '/root/repo')
+import os
 import torch
+import hypergrep_amd
+if os.environ.get("HG_LIB"):  # an experiment / earlier build of the native library (hypergrep_amd/build.py HG_BUILD_OUT)
+    hypergrep_amd.configure_libraries(libhs=os.path.abspath(os.environ["HG_LIB"]))
 from hypergrep_amd import benchspec, device
 patterns, needles, hpm = benchspec.c3_spec()
 SETS = (["ERROR"], ["foo|bar"], ["status=5[0-9]{2}"], ["ERROR", "WARN", "panic", "fail"], ["[0-9]+\\.[0-9]+"], ["fail.*time"], ["\\bGET\\b"], ["[a-z]+@[a-z]+"], ["\\b[0-9]{3}\\b"], ["[0-9]+\\.[0-9]+", "[a-z]+@[a-z]+", "\\b[0-9]{3}\\b", "=7"],
