@@ -1183,6 +1183,7 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
       }
       i = j;
     }
+    db.wtab_first = (distinct > 0 && static_cast<size_t>(db.shared_windows) * 20 <= distinct) ? 1u : 0u;
   }
 
   // LDS filter over the distinct window values (single-probe slots below; two-slot cells in wide mode).

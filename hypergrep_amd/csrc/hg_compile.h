@@ -21,6 +21,10 @@ struct HgDb {
   std::vector<HgWinBucket> wtab;      // direct window table (hg_db.h): wtab_mask + 1 buckets
   uint32_t wtab_mask = 0;
   uint32_t shared_windows = 0;        // window values that several literals share (they take the discriminated buckets)
+  uint32_t wtab_first = 0;            // at most one window value in twenty is shared: the verify pass asks the table first (config 5:
+                                      // 190 of 16 384; 14.9 against 16.4 ms per 32 GiB).  Else it starts at the discriminated buckets, as
+                                      // it did before the table existed: for a shared window the table is one more fetch in front of that
+                                      // chain (config 3, 150 of 1400 values, the class expressions' stems: 315 against 225 us per 8 GiB)
   std::vector<uint32_t> filter;      // 1 << filter_log2 slots holding hash C of the owning window (staged in LDS by the stream kernel)
   uint32_t filter_log2 = HG_FILTER_MIN_LOG2;
   uint32_t filter_wide = 0;          // 1: two 16-bit fingerprints per slot, no neighbour conditions (large pattern sets)

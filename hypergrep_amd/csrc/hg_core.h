@@ -54,6 +54,7 @@ struct HgDbView {
   const HgWindow *windows2;
   const HgWinBucket *wtab;       // direct window table (hg_db.h)
   uint32_t wtab_mask;
+  uint32_t wtab_first;           // the verify pass asks the table first (sets whose windows mostly have ONE owner); else it goes straight to the discriminated buckets
   const uint32_t *slow;
   uint32_t npatterns, nslow, fold_mask;
   uint32_t window_mask;  // 0xFFFFFFFF, or 0x00FFFFFF for 3-byte windows

@@ -161,6 +161,7 @@ int HgScanner::create(std::shared_ptr<const HgDb> db, int device, HgScanner **ou
   s->view_.windows2 = static_cast<const HgWindow *>(s->d_windows2_);
   s->view_.wtab = static_cast<const HgWinBucket *>(s->d_wtab_);
   s->view_.wtab_mask = db->wtab_mask;
+  s->view_.wtab_first = db->wtab_first;
   s->view_.slow = static_cast<const uint32_t *>(s->d_slow_);
   s->view_.npatterns = static_cast<uint32_t>(db->patterns.size());
   s->view_.nslow = static_cast<uint32_t>(db->slow.size());

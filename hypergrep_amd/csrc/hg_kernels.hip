@@ -873,12 +873,18 @@ __device__ __forceinline__ void verify_stage_flush(const HgConfirmArgs &a, Verif
 // that matched (the same 32-byte sector).  Returns the owner's factor_off, HG_WTAB_SHARED or HG_WTAB_EMPTY.
 __device__ __forceinline__ uint32_t wtab_lookup(const HgWinBucket *tab, uint32_t bucket_mask, uint32_t folded) {
   for (uint32_t b = hg_wtab_bucket(folded, bucket_mask);; b = (b + 1u) & bucket_mask) {
-    const uint4 v = *reinterpret_cast<const uint4 *>(tab[b].value);
+    const uint4 *e = reinterpret_cast<const uint4 *>(tab + b);
+    uint4 v = e[0], p = e[1];  // the four values and their payloads: one 32-byte sector, both loads in flight together
+    // (all eight words are wanted HERE: left to itself the compiler loads value[0], then value[1..2] behind a branch, then the
+    // payload behind another — three dependent round trips where one was meant; config 3's verify pass took 510 us per 8 GiB
+    // with that against 223 without the table)
+    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w), "+v"(p.x), "+v"(p.y), "+v"(p.z), "+v"(p.w));
     // (an empty slot holds value 0 and payload EMPTY: a match on an empty slot's value returns EMPTY, which is right)
-    const uint32_t k = v.x == folded ? 0u : (v.y == folded ? 1u : (v.z == folded ? 2u : 3u));
-    const uint32_t payload = tab[b].factor_off[k];
-    if (k < 3u || v.w == folded) return payload;  // found (or the empty slot that holds value 0)
-    if (payload == HG_WTAB_EMPTY) return HG_WTAB_EMPTY;  // not found and the bucket has room left: the value would be here
+    if (v.x == folded) return p.x;
+    if (v.y == folded) return p.y;
+    if (v.z == folded) return p.z;
+    if (v.w == folded) return p.w;
+    if (p.w == HG_WTAB_EMPTY) return HG_WTAB_EMPTY;  // the bucket has room left: the value would be here (buckets fill front to back)
   }
 }
 // Does the literal of `f` (len bytes, HgFactor) occur at text[fs, fs + len)?  The record is one cache line: the literal as
@@ -936,22 +942,30 @@ __device__ __forceinline__ void verify_body(const HgConfirmArgs &a, VerifyStage 
     const uint32_t base = base0 + wave * 64u;
     const uint32_t i = base + lane;
     HgCand c{0, 0, 0};
-    uint32_t j0 = 0, cnt = 0, folded = 0, direct_fo = 0;
+    uint32_t j0 = 0, cnt = 0, folded = 0, direct_fo = 0, disc_h = 0, disc_d = 0;
     bool direct = false, shared = false;
     if (i < n) {
       c = cseg[i];
       folded = (c.word | fold) & a.db.window_mask;
       // the direct table: a value it does not hold belongs to no literal (the filter's false positives end here, one fetch
       // each); a value with one owner names it; only windows that several literals share go through the discriminated buckets
-      direct_fo = wtab_lookup(a.db.wtab, a.db.wtab_mask, folded);
-      shared = direct_fo == HG_WTAB_SHARED;
-      direct = !shared && direct_fo != HG_WTAB_EMPTY;
+      // (the shared windows' discriminator word is fetched beside the table bucket, not behind it: a shared window's chain of
+      // fetches is then no longer than it was before the table existed — config 3's class expressions share their windows)
+      disc_h = hg_hash_window(folded);
+      disc_d = a.db.disc[disc_h];
+      if (a.db.wtab_first) {  // (uniform: a property of the pattern set, HgDb::wtab_first)
+        direct_fo = wtab_lookup(a.db.wtab, a.db.wtab_mask, folded);
+        shared = direct_fo == HG_WTAB_SHARED;
+        direct = !shared && direct_fo != HG_WTAB_EMPTY;
+      } else {
+        shared = true;
+      }
       if (direct) cnt = 1;
     }
     if (shared) {
       // the group's discriminator dword of the text selects the bucket (hg_disc_range, with one aligned dword load)
-      const uint32_t h = hg_hash_window(folded);
-      const uint32_t d = a.db.disc[h];
+      const uint32_t h = disc_h;
+      const uint32_t d = disc_d;
       const uint32_t sel = d >> 8;
       uint32_t key = 0;
       bool inside = true;

@@ -148,6 +148,7 @@ static HgDbView view_of(HgDb *db) {
   v.windows2 = db->windows2.data();
   v.wtab = db->wtab.data();
   v.wtab_mask = db->wtab_mask;
+  v.wtab_first = db->wtab_first;
   v.slow = db->slow.data();
   v.npatterns = db->patterns.size();
   v.nslow = db->slow.size();

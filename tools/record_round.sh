@@ -30,7 +30,7 @@ for name in ("FETCH_SIZE", "WRITE_SIZE"):
     out[name] = agg
 import json
 f, w = out["FETCH_SIZE"].get("hg_stream_kernel"), out["WRITE_SIZE"].get("hg_stream_kernel")
-# average duration of hg_stream_kernel in the --kernel-trace --stats run of the same command (bench.py prices `frac` with it)
+# average duration of hg_stream_kernel in the --kernel-trace --stats run of the same command (bench.py prices its roofline fraction with it)
 kms = None
 for line in open("$O/kernel_stats.txt"):
     parts = line.split()
