@@ -1663,6 +1663,8 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
         h.nsources = static_cast<uint32_t>(xlist.size() - 1);
         h.nranges = static_cast<uint32_t>(xt.size() / 2);
         std::memcpy(&db->pool[hdr_off], &h, sizeof h);
+        const uint64_t stage = 64ull + static_cast<uint64_t>(nw) * (ncls + 4u + (ctxfree ? 1u : 36u));  // (hg_huge.hip huge_stage_words)
+        if (stage <= HG_HUGE_STAGE_MAX) db->huge_stage_words = std::max<uint32_t>(db->huge_stage_words, static_cast<uint32_t>(stage));
       }
       if (!huge) db->max_nw = std::max(db->max_nw, nw);
       db->max_id = std::max(db->max_id, p.id);

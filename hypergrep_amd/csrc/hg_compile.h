@@ -43,6 +43,8 @@ struct HgDb {
   uint32_t max_nw = 1;               // state words of the largest automaton with dense tables (<= HG_MAX_W)
   uint32_t nhuge = 0;                // expressions with sparse tables (more than HG_MAX_NODES nodes: hg_db.h HgHugeHeader)
   uint32_t huge_max_nw = 0;          // ... and the state words of the largest of them (sizes the LDS of the huge routines)
+  uint32_t huge_stage_words = 0;     // LDS words the huge routines get for a staged copy of ONE expression's per-byte tables: the largest
+                                     // need among the huge expressions that fits HG_HUGE_STAGE_MAX (an expression that needs more reads L2)
   uint32_t nslow_huge = 0;           // huge always-on expressions: the LAST nslow_huge entries of `slow`
   uint32_t max_id = 0;               // largest report id (sizes the sort key)
   uint32_t n_confirm_mode[HG_CONFIRM_MODES] = {};  // tier-0 patterns by confirm routine (hg_confirm_mode)

@@ -30,6 +30,7 @@ constexpr uint32_t HG_MAX_W = HG_MAX_NODES / 32;
 // Limits: the expression's Thompson program size (what the oracle and Hyperscan's graph limits bound) and the node count.
 constexpr uint32_t HG_HUGE_MAX_PROGRAM = 400000;   // Thompson instructions of the expression (oracle/orx.c ORX_MAX_INST restates the same bound)
 constexpr uint32_t HG_HUGE_MAX_NODES = 1u << 19;   // (position, entry condition) nodes: 16384 state words = 64 KiB of LDS per state copy
+constexpr uint32_t HG_HUGE_STAGE_MAX = 12288;      // words (48 KiB) of per-byte tables a huge routine stages in LDS
 constexpr uint32_t HG_HUGE_MAX_EDGES = 1u << 22;   // automaton edges the compiler will hold (quadratic constructions such as (a?b?c?...){n} stop here)
 constexpr uint32_t HG_MAX_PATTERNS = 1u << 24;  // pattern index and window offset share one word in the verified-occurrence records
 constexpr uint32_t HG_ALWAYS_ON_FAST_MAX_LEN = 64;  // always-on patterns up to this match length use a fixed lead-in, longer / unbounded ones their line's start

@@ -54,10 +54,10 @@ __global__ void hg_scatter_kernel(const HgHit *hits, const HgHitAux *aux, const 
                                   HgHit *oh, HgHitAux *oa, uint32_t *count);
 
 // huge automata (hg_huge.hip)
-size_t hg_huge_lds_bytes(uint32_t nw_max);
-bool hg_launch_confirm_huge(const HgConfirmArgs &a, uint32_t grid, uint32_t nw_max, void *claim, uint32_t claim_mask, hipStream_t stream);
-bool hg_launch_always_on_huge(const HgConfirmArgs &a, uint32_t grid, uint32_t nw_max, uint32_t first, uint32_t last, hipStream_t stream);
-bool hg_launch_block_huge(const HgConfirmArgs &a, uint32_t grid, uint32_t nw_max, const uint32_t *pattern_flags, hipStream_t stream);
+size_t hg_huge_lds_bytes(uint32_t nw_max, uint32_t stage_cap);
+bool hg_launch_confirm_huge(const HgConfirmArgs &a, uint32_t grid, uint32_t nw_max, uint32_t stage_cap, void *claim, uint32_t claim_mask, hipStream_t stream);
+bool hg_launch_always_on_huge(const HgConfirmArgs &a, uint32_t grid, uint32_t nw_max, uint32_t stage_cap, uint32_t first, uint32_t last, hipStream_t stream);
+bool hg_launch_block_huge(const HgConfirmArgs &a, uint32_t grid, uint32_t nw_max, uint32_t stage_cap, const uint32_t *pattern_flags, hipStream_t stream);
 
 namespace {
 constexpr int TS_BLOCK_TILES = 1024;  // must match hg_kernels.hip (256 threads x 4 tiles)
@@ -556,7 +556,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
         always_blocks = std::max<uint32_t>(static_cast<uint32_t>((db_->patterns.size() + 255) / 256), std::min<uint32_t>(db_->nhuge, 1024u));
         ca.hit_seg_cap = hit_cap_ / always_blocks;
         hipLaunchKernelGGL(hg_block_scan_kernel, dim3(static_cast<uint32_t>((db_->patterns.size() + 255) / 256)), dim3(256), 0, side, ca, d_pflags_);
-        if (db_->nhuge && !hg_launch_block_huge(ca, std::min<uint32_t>(db_->nhuge, 1024u), db_->huge_max_nw, d_pflags_, side)) {
+        if (db_->nhuge && !hg_launch_block_huge(ca, std::min<uint32_t>(db_->nhuge, 1024u), db_->huge_max_nw, db_->huge_stage_words, d_pflags_, side)) {
           err_ = "the huge-automaton kernel cannot have its LDS";
           return HG_ERR_HIP;
         }
@@ -584,7 +584,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
           if (knobs_.confirm_blocks_per_cu) per_cu = static_cast<uint32_t>(knobs_.confirm_blocks_per_cu);
           const uint32_t mode_blocks = std::max<uint32_t>(HG_DEFER_SHARDS, static_cast<uint32_t>(num_cus_) * per_cu * (256 / HG_CONFIRM_THREADS));  // per_cu counts 256 lanes
           // huge automata (confirm mode 4): one-wave workgroups, as many per CU as their LDS allows (8 at most)
-          const uint32_t huge_blocks = db_->n_confirm_mode[4] ? std::max<uint32_t>(HG_DEFER_SHARDS, static_cast<uint32_t>(num_cus_) * static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(8, (160u << 10) / std::max<size_t>(hg_huge_lds_bytes(db_->huge_max_nw), 1))))) : 0u;
+          const uint32_t huge_blocks = db_->n_confirm_mode[4] ? std::max<uint32_t>(HG_DEFER_SHARDS, static_cast<uint32_t>(num_cus_) * static_cast<uint32_t>(std::max<size_t>(1, std::min<size_t>(8, (160u << 10) / std::max<size_t>(hg_huge_lds_bytes(db_->huge_max_nw, db_->huge_stage_words), 1))))) : 0u;
           confirm_blocks = std::max(std::max(mode_blocks * std::max(fast_modes, 1u), verify_blocks), huge_blocks);  // the largest grid that stages hits
           ca.hit_seg_cap = hit_cap_ / confirm_blocks;
           ca.deferred = d_deferred_;
@@ -605,7 +605,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
           if (db_->n_confirm_mode[3]) hipLaunchKernelGGL(hg_confirm_generic_kernel, dim3(mode_blocks), dim3(256), 0, side, ca);
           if (huge_blocks && ((mode_mask >> 4) & 1u)) {
             HG_TRY(hipMemsetAsync(d_huge_claim_, 0, huge_claim_slots_ * 8, side), "memset claim table");
-            if (!hg_launch_confirm_huge(ca, huge_blocks, db_->huge_max_nw, d_huge_claim_, static_cast<uint32_t>(huge_claim_slots_ - 1), side)) {
+            if (!hg_launch_confirm_huge(ca, huge_blocks, db_->huge_max_nw, db_->huge_stage_words, d_huge_claim_, static_cast<uint32_t>(huge_claim_slots_ - 1), side)) {
               err_ = "the huge-automaton kernel cannot have its LDS";
               return HG_ERR_HIP;
             }
@@ -614,7 +614,9 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
         }
         if (!db_->slow.empty()) {
           always_blocks = static_cast<uint32_t>(std::min<uint64_t>((span + 3) / 4, static_cast<uint64_t>(num_cus_) * 8));
-          ca.hit_seg_cap = hit_cap_ / always_blocks;
+          // (huge automata: one-wave workgroups, four per SIMD — the routine is a chain of LDS reads and ballots per byte)
+          const uint32_t huge_always_blocks = db_->nslow_huge ? static_cast<uint32_t>(std::min<uint64_t>(span, static_cast<uint64_t>(num_cus_) * 16)) : 0u;
+          ca.hit_seg_cap = hit_cap_ / std::max(always_blocks, huge_always_blocks);
           const uint32_t nfast = db_->nslow_fast, nhuge = db_->nslow_huge, nall = static_cast<uint32_t>(db_->slow.size()) - nhuge;  // [fast | scalar | huge]
           if (nfast) {
             // the match list lives in the (by now idle) verified-occurrence lists: cand_cap_ entries at least, a segment per block
@@ -625,10 +627,11 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
             hipLaunchKernelGGL(hg_always_on_finish_kernel, dim3(always_blocks), dim3(256), 0, side, ca);
           }
           if (nall > nfast) hipLaunchKernelGGL(hg_always_on_kernel, dim3(always_blocks), dim3(256), 0, side, ca, nfast, nall);
-          if (nhuge && !hg_launch_always_on_huge(ca, always_blocks, db_->huge_max_nw, nall, nall + nhuge, side)) {
+          if (nhuge && !hg_launch_always_on_huge(ca, huge_always_blocks, db_->huge_max_nw, db_->huge_stage_words, nall, nall + nhuge, side)) {
             err_ = "the huge-automaton kernel cannot have its LDS";
             return HG_ERR_HIP;
           }
+          always_blocks = std::max(always_blocks, huge_always_blocks);  // (sizes the regrowth of the staging segments)
           HG_TRY(hipGetLastError(), "hg_always_on_kernel launch");
         }
       }

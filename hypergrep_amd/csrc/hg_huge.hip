@@ -138,15 +138,19 @@ __device__ __forceinline__ void huge_run(const HgHugeView &v, uint32_t *S, uint3
     // ---- 3: the byte's class and context select who survives
     const uint32_t *r = v.reach + hg_huge_class(v, c) * nw;
     const uint32_t *m = v.amask + (pc * 4 + cc) * nw;
-    uint32_t mx = 0;
-    for (uint32_t w = lane; w < lim3; w += 64) {
-      uint32_t x = T[w] & r[w];
-      if (!v.ctxfree) x &= m[w];
-      T[w] = 0;
-      S[w] = x;
-      if (x) mx = w + 1;
+    whi = 0;
+    for (uint32_t base = 0; base < lim3; base += 64) {  // (uniform trip count: the highest live word comes from ballots, no cross-lane reduction)
+      const uint32_t w = base + lane;
+      uint32_t x = 0;
+      if (w < lim3) {
+        x = T[w] & r[w];
+        if (!v.ctxfree) x &= m[w];
+        T[w] = 0;
+        S[w] = x;
+      }
+      const uint64_t live = __builtin_amdgcn_ballot_w64(x != 0);
+      if (live) whi = base + 64u - static_cast<uint32_t>(__builtin_clzll(live));
     }
-    whi = wave_max_u32(mx);
     __syncthreads();
     pc = hg_prev_ctx(c);
   }
@@ -154,6 +158,187 @@ __device__ __forceinline__ void huge_run(const HgHugeView &v, uint32_t *S, uint3
   uint32_t any = 0;
   for (uint32_t w = lane; w < whi; w += 64) any |= S[w] & accw[w];
   if (__builtin_amdgcn_ballot_w64(any != 0) && lane == 0) emit(static_cast<uint32_t>(len));
+}
+
+// The tables huge_run reads for every byte — class map, reach rows, init, shift mask, exception sources / ranks, accept and entry
+// masks — copied into LDS when they fit `cap_words` (the exception lists stay in HBM / L2: they are read when an exception
+// fires).  From L2 every phase of a byte waits for a fetch (4.3 us per byte and wave measured on [a-z]{2000}x: 1.8 GiB/s for
+// the always-on pass); staged, the phases wait for LDS.  Returns the view to run with.
+__device__ __forceinline__ uint32_t huge_stage_words(const HgHugeView &v) { return 64u + v.nw * (v.ncls + 4u + (v.ctxfree ? 1u : 36u)); }
+__device__ __forceinline__ HgHugeView huge_stage(const HgHugeView &v, uint32_t *lds, uint32_t cap_words, uint32_t lane) {
+  if (huge_stage_words(v) > cap_words) return v;
+  HgHugeView s = v;
+  uint32_t at = 0;
+  auto put = [&](const uint32_t *src, uint32_t words) -> const uint32_t * {
+    for (uint32_t i = lane; i < words; i += 64) lds[at + i] = src[i];
+    const uint32_t *dst = lds + at;
+    at += words;
+    return dst;
+  };
+  s.cls = put(v.cls, 64u);
+  s.reach = put(v.reach, v.ncls * v.nw);
+  s.init = put(v.init, v.nw);
+  s.smask = put(v.smask, v.nw);
+  s.xsrc = put(v.xsrc, v.nw);
+  s.xrank = put(v.xrank, v.nw);
+  s.acc = put(v.acc, (v.ctxfree ? 1u : 20u) * v.nw);
+  if (!v.ctxfree) s.amask = put(v.amask, 16u * v.nw);
+  __syncthreads();
+  return s;
+}
+
+// ---- the register-resident routine: automata of at most 64 K words (K = 1, 2, 4: up to 8192 nodes) whose tables are staged ------
+// Lane l holds the state words l, l + 64, ... in REGISTERS, with their init / shift / exception-source masks (and the accept mask
+// of a condition-free automaton): they never change during a run.  A byte is then: accept test (ballot), shift edges (the carry
+// between neighbouring words is a DPP wave shift), one LDS read per word for the byte's reach row (plus the context rows when the
+// automaton has boundary conditions), ballots for liveness.  Exception edges are rare: only when some lane has a live exception
+// source does the step go through the LDS copy of the next state (the atomic-OR procedure of huge_run).  Measured on
+// [a-z]{2000}x, always-on: the LDS-resident routine above ran at 0.75 us per byte and wave (2.6 GiB/s).
+using lds_u32 = __attribute__((address_space(3))) uint32_t;
+struct HugeStaged {  // staged copies (huge_stage's layout), as LDS pointers
+  const lds_u32 *cls, *reach, *acc, *amask;
+};
+template <int K, typename Emit>
+__device__ __forceinline__ void huge_run_reg(const HgHugeView &v, const HugeStaged &t, lds_u32 *T, const uint8_t *data, uint64_t len, uint64_t from, uint64_t upto, bool single,
+                                             uint32_t lane, Emit &&emit) {
+  const uint32_t nw = v.nw;
+  uint32_t s[K], c_init[K], c_smask[K], c_xsrc[K], c_acc[K];
+#pragma unroll
+  for (int k = 0; k < K; k++) {
+    const uint32_t w = lane + 64u * k;
+    const bool in = w < nw;
+    s[k] = 0;
+    c_init[k] = in ? v.init[w] : 0u;
+    c_smask[k] = in ? v.smask[w] : 0u;
+    c_xsrc[k] = in ? v.xsrc[w] : 0u;
+    c_acc[k] = (in && v.ctxfree) ? v.acc[w] : 0u;
+  }
+  uint32_t pc = from ? hg_prev_ctx(data[from - 1]) : HG_PC_START;
+  uint32_t cv = 0;
+  uint64_t i0 = from;
+  bool alive = false;
+  for (uint64_t i = from; i < len; i++) {
+    if (i >= upto && !alive) return;
+    if (i == from || i - i0 == 64) {
+      i0 = i;
+      cv = i0 + lane < len ? data[i0 + lane] : 0u;
+    }
+    const uint32_t c = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(cv), static_cast<int>(i - i0)));
+    const uint32_t cc = c == '\n' ? (i + 1 == len ? HG_NC_NLFINAL : HG_NC_NL) : (hg_is_word(c) ? HG_NC_WORD : HG_NC_OTHER);
+    const uint32_t cls = __builtin_amdgcn_readfirstlane((t.cls[c >> 2] >> ((c & 3u) * 8u)) & 0xFFu);
+    const bool inject = i < upto;
+    // the byte's rows, one LDS read per word
+    uint32_t r[K], m[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const uint32_t w = lane + 64u * k, wc = w < nw ? w : 0u;
+      r[k] = w < nw ? t.reach[cls * nw + wc] : 0u;
+      m[k] = v.ctxfree ? 0xFFFFFFFFu : t.amask[(pc * 4 + cc) * nw + wc];
+    }
+    // accept test on the current state
+    if (alive) {
+      uint32_t any = 0;
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const uint32_t w = lane + 64u * k, wc = w < nw ? w : 0u;
+        any |= s[k] & (v.ctxfree ? c_acc[k] : t.acc[(pc * 5 + cc) * nw + wc]);
+      }
+      if (__builtin_amdgcn_ballot_w64(any != 0)) {
+        if (lane == 0) emit(static_cast<uint32_t>(i));
+        if (single) return;
+      }
+    }
+    // shift edges: word w's top bit moves into word w + 1 (the next lane; lane 63's into lane 0 of the next slab)
+    uint32_t nx[K], exc = 0;
+    uint32_t carry_slab = 0;  // top bit of the previous slab's lane 63
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const uint32_t x = s[k] & c_smask[k];
+      const uint32_t top = x >> 31;
+      uint32_t carry = __builtin_amdgcn_update_dpp(0u, top, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);  // lane l gets lane l - 1's, lane 0 gets 0
+      if (lane == 0) carry = carry_slab;
+      carry_slab = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(top), 63));
+      nx[k] = (inject ? c_init[k] : 0u) | (x << 1) | carry;
+      exc |= s[k] & c_xsrc[k];
+    }
+    if (__builtin_amdgcn_ballot_w64(exc != 0)) {  // (rare) exception edges: through the LDS copy, targets may lie anywhere
+#pragma unroll
+      for (int k = 0; k < K; k++)
+        if (lane + 64u * k < nw) T[lane + 64u * k] = nx[k];
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const uint32_t w = lane + 64u * k;
+        uint32_t x = s[k] & c_xsrc[k];
+        if (!x) continue;
+        const uint32_t base = v.xrank[w];
+        while (x) {
+          const uint32_t b = hg_ctz(x);
+          x &= x - 1;
+          const uint32_t kk = base + hg_popc(c_xsrc[k] & ((1u << b) - 1u));
+          for (uint32_t q = v.xlist[kk], q1 = v.xlist[kk + 1]; q < q1; q++) {
+            const uint32_t lo = v.xt[2 * q], hi = v.xt[2 * q + 1];
+            const uint32_t w0 = lo >> 5, w1 = hi >> 5;
+            for (uint32_t tw = w0; tw <= w1; tw++)
+              __hip_atomic_fetch_or(&T[tw], (tw == w0 ? hg_bits_from(lo) : 0xFFFFFFFFu) & (tw == w1 ? hg_bits_upto(hi) : 0xFFFFFFFFu), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < K; k++)
+        if (lane + 64u * k < nw) nx[k] = T[lane + 64u * k];
+      __syncthreads();
+    }
+    uint32_t live = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      s[k] = nx[k] & r[k] & m[k];
+      live |= s[k];
+    }
+    alive = __builtin_amdgcn_ballot_w64(live != 0) != 0;
+    pc = hg_prev_ctx(c);
+  }
+  if (alive) {
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+      const uint32_t w = lane + 64u * k, wc = w < nw ? w : 0u;
+      any |= s[k] & (v.ctxfree ? c_acc[k] : t.acc[(pc * 5 + HG_NC_END) * nw + wc]);
+    }
+    if (__builtin_amdgcn_ballot_w64(any != 0) && lane == 0) emit(static_cast<uint32_t>(len));
+  }
+}
+
+// One expression made ready for a wave: its view (staged where that fits) and which routine runs it.
+struct HugeUnit {
+  HgHugeView v;
+  HugeStaged t;
+  uint32_t k;  // words per lane of the register-resident routine (1, 2, 4), 0: the LDS-resident routine
+};
+__device__ __forceinline__ HugeUnit huge_prepare(const HgHugeView &view, uint32_t *stage, uint32_t cap_words, uint32_t lane) {
+  HugeUnit u;
+  const bool fits = huge_stage_words(view) <= cap_words;
+  u.v = huge_stage(view, stage, cap_words, lane);
+  u.k = 0;
+  u.t = HugeStaged{nullptr, nullptr, nullptr, nullptr};
+  if (fits && view.nw <= 256u) {
+    u.k = view.nw <= 64u ? 1u : (view.nw <= 128u ? 2u : 4u);
+    // huge_stage's layout: cls[64] reach[ncls * nw] init smask xsrc xrank [nw each] acc[(1 | 20) * nw] amask[16 * nw]
+    const lds_u32 *base = (const lds_u32 *)stage;
+    u.t.cls = base;
+    u.t.reach = base + 64u;
+    u.t.acc = base + 64u + view.nw * (view.ncls + 4u);
+    u.t.amask = u.t.acc + (view.ctxfree ? 1u : 20u) * view.nw;
+  }
+  return u;
+}
+template <typename Emit>
+__device__ __forceinline__ void huge_run_unit(const HugeUnit &u, uint32_t *S, uint32_t *T, const uint8_t *data, uint64_t len, bool single, uint32_t lane, Emit &&emit) {
+  if (u.k == 1) huge_run_reg<1>(u.v, u.t, (lds_u32 *)T, data, len, 0, len, single, lane, emit);
+  else if (u.k == 2) huge_run_reg<2>(u.v, u.t, (lds_u32 *)T, data, len, 0, len, single, lane, emit);
+  else if (u.k == 4) huge_run_reg<4>(u.v, u.t, (lds_u32 *)T, data, len, 0, len, single, lane, emit);
+  else huge_run(u.v, S, T, data, len, 0, len, single, lane, emit);
 }
 
 // (piece start, expression) -> claimed by the first caller.  Open addressing, linear probing; the table has at least twice as
@@ -169,11 +354,11 @@ __device__ __forceinline__ bool claim_piece(unsigned long long *table, uint32_t 
   }
 }
 
-extern __shared__ uint32_t s_dyn[];  // S[nw_max], T[nw_max]
+extern __shared__ uint32_t s_dyn[];  // S[nw_max], T[nw_max], staged tables [stage_cap]
 
 // Tier 0 (confirm mode 4).  Same unit of work as hg_confirm (hg_core.h): locate the piece that holds the verified occurrence,
 // trim it, run the expression over the whole piece — once per (piece, expression).
-__global__ __launch_bounds__(64) void hg_confirm_huge_kernel(HgConfirmArgs a, uint32_t nw_max, unsigned long long *claim, uint32_t claim_mask) {
+__global__ __launch_bounds__(64) void hg_confirm_huge_kernel(HgConfirmArgs a, uint32_t nw_max, uint32_t stage_cap, unsigned long long *claim, uint32_t claim_mask) {
   __shared__ uint32_t s_n, s_base;
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
@@ -182,6 +367,8 @@ __global__ __launch_bounds__(64) void hg_confirm_huge_kernel(HgConfirmArgs a, ui
   const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
   const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n};
   constexpr uint32_t MODE = 4;
+  uint32_t staged_pattern = HG_NONE32;  // the expression whose tables sit in LDS
+  HugeUnit unit{};
   const uint32_t shard = blockIdx.x % HG_DEFER_SHARDS, peer = blockIdx.x / HG_DEFER_SHARDS, peers = (gridDim.x + HG_DEFER_SHARDS - 1 - shard) / HG_DEFER_SHARDS;
   const HgDeferred *dlist = a.deferred + (static_cast<uint64_t>(a.list_of_mode[MODE]) * HG_DEFER_SHARDS + shard) * a.defer_shard_cap;
   uint32_t n = a.defer_count[MODE * HG_DEFER_SHARDS + shard];
@@ -201,17 +388,21 @@ __global__ __launch_bounds__(64) void hg_confirm_huge_kernel(HgConfirmArgs a, ui
     wave_trim_piece(a.text, ps, limit, lane, pa, pz);
     if (pz <= pa) continue;
     const HgPattern &p = a.db.patterns[pattern];
-    const HgHugeView v = hg_huge_view(a.db.pool, p);
+    if (pattern != staged_pattern) {
+      __syncthreads();  // (the previous expression's tables are no longer read)
+      unit = huge_prepare(hg_huge_view(a.db.pool, p), s_dyn + 2 * nw_max, stage_cap, lane);
+      staged_pattern = pattern;
+    }
     const uint32_t id = p.id, len = static_cast<uint32_t>(pz - pa);
     const bool single = p.single != 0;
-    huge_run(v, S, T, a.text + pa, len, 0, len, single, lane, [&](uint32_t to) { sink.push(a, line_no, id, to, pa, len, pattern, single); });
+    huge_run_unit(unit, S, T, a.text + pa, len, single, lane, [&](uint32_t to) { sink.push(a, line_no, id, to, pa, len, pattern, single); });
   }
   flush_hits(a, &s_n, &s_base);
 }
 
 // Tier 1: the huge entries [first, last) of the always-on list on every piece of every line that starts in the wave's tiles
 // (hg_scan_line_always_on, hg_core.h, with the whole wave on one piece).
-__global__ __launch_bounds__(64) void hg_always_on_huge_kernel(HgConfirmArgs a, uint32_t nw_max, uint32_t first, uint32_t last) {
+__global__ __launch_bounds__(64) void hg_always_on_huge_kernel(HgConfirmArgs a, uint32_t nw_max, uint32_t stage_cap, uint32_t first, uint32_t last) {
   __shared__ uint32_t s_n, s_base;
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
@@ -220,6 +411,8 @@ __global__ __launch_bounds__(64) void hg_always_on_huge_kernel(HgConfirmArgs a, 
   const uint64_t seg0 = static_cast<uint64_t>(blockIdx.x) * a.hit_seg_cap;
   const HitSink sink{a.tmp_hits + seg0, a.tmp_aux + seg0, a.hit_seg_cap, &s_n};
   const bool small = a.bs1 < HG_TILE_BYTES;
+  uint32_t staged_pattern = HG_NONE32;  // (ONE huge always-on expression, the usual case: staged once for the whole kernel)
+  HugeUnit unit{};
   for (uint64_t tile = a.tile_begin + blockIdx.x; tile < a.tile_end; tile += gridDim.x) {
     const uint64_t tile_start = tile << HG_TILE_SHIFT;
     uint32_t rank_base = 0;  // '\n' bytes in [tile_start, tile_start + off)
@@ -243,10 +436,14 @@ __global__ __launch_bounds__(64) void hg_always_on_huge_kernel(HgConfirmArgs a, 
             for (uint32_t j = first; j < last; j++) {
               const uint32_t pi = a.db.slow[j];
               const HgPattern &pat = a.db.patterns[pi];
-              const HgHugeView v = hg_huge_view(a.db.pool, pat);
+              if (pi != staged_pattern) {
+                __syncthreads();
+                unit = huge_prepare(hg_huge_view(a.db.pool, pat), s_dyn + 2 * nw_max, stage_cap, lane);
+                staged_pattern = pi;
+              }
               const uint32_t id = pat.id;
               const bool single = pat.single != 0;
-              huge_run(v, S, T, a.text + pa, len, 0, len, single, lane, [&](uint32_t to) { sink.push(a, line_no, id, to, pa, len, pi, single); });
+              huge_run_unit(unit, S, T, a.text + pa, len, single, lane, [&](uint32_t to) { sink.push(a, line_no, id, to, pa, len, pi, single); });
             }
           }
           // where does the piece end?  after its '\n', else at limit (a forced break: the line goes on as the next piece).
@@ -269,7 +466,7 @@ __global__ __launch_bounds__(64) void hg_always_on_huge_kernel(HgConfirmArgs a, 
 
 // Block mode (Face A, hs_scan): the whole buffer is ONE scan unit.  A wave per huge expression that is always-on or whose
 // required literal occurs in the block (pattern_flags, hg_block_mark_kernel).
-__global__ __launch_bounds__(64) void hg_block_huge_kernel(HgConfirmArgs a, uint32_t nw_max, const uint32_t *pattern_flags) {
+__global__ __launch_bounds__(64) void hg_block_huge_kernel(HgConfirmArgs a, uint32_t nw_max, uint32_t stage_cap, const uint32_t *pattern_flags) {
   __shared__ uint32_t s_n, s_base;
   if (threadIdx.x == 0) s_n = 0;
   __syncthreads();
@@ -283,10 +480,11 @@ __global__ __launch_bounds__(64) void hg_block_huge_kernel(HgConfirmArgs a, uint
     if (pat.nw <= HG_MAX_W) continue;
     if (seen++ % gridDim.x != blockIdx.x) continue;
     if (pat.tier == 0 && !pattern_flags[p]) continue;
-    const HgHugeView v = hg_huge_view(a.db.pool, pat);
+    __syncthreads();
+    const HugeUnit unit = huge_prepare(hg_huge_view(a.db.pool, pat), s_dyn + 2 * nw_max, stage_cap, lane);
     const uint32_t id = pat.id;
     const bool single = pat.single != 0;
-    huge_run(v, S, T, a.text, a.nbytes, 0, a.nbytes, single, lane, [&](uint32_t to) { sink.push(a, 0, id, to, 0, static_cast<uint32_t>(a.nbytes), p, single); });
+    huge_run_unit(unit, S, T, a.text, a.nbytes, single, lane, [&](uint32_t to) { sink.push(a, 0, id, to, 0, static_cast<uint32_t>(a.nbytes), p, single); });
   }
   flush_hits(a, &s_n, &s_base);
 }
@@ -299,24 +497,24 @@ bool allow_lds(K kernel, size_t bytes) {
 
 }  // namespace
 
-// LDS of a huge-automaton workgroup: two copies of the largest automaton's state words.
-size_t hg_huge_lds_bytes(uint32_t nw_max) { return static_cast<size_t>(nw_max) * 8u; }
+// LDS of a huge-automaton workgroup: two copies of the largest automaton's state words + the staged tables.
+size_t hg_huge_lds_bytes(uint32_t nw_max, uint32_t stage_cap) { return (static_cast<size_t>(nw_max) * 2u + stage_cap) * 4u; }
 
-bool hg_launch_confirm_huge(const HgConfirmArgs &a, uint32_t grid, uint32_t nw_max, void *claim, uint32_t claim_mask, hipStream_t stream) {
-  const size_t lds = hg_huge_lds_bytes(nw_max);
+bool hg_launch_confirm_huge(const HgConfirmArgs &a, uint32_t grid, uint32_t nw_max, uint32_t stage_cap, void *claim, uint32_t claim_mask, hipStream_t stream) {
+  const size_t lds = hg_huge_lds_bytes(nw_max, stage_cap);
   if (!allow_lds(hg_confirm_huge_kernel, lds)) return false;
-  hipLaunchKernelGGL(hg_confirm_huge_kernel, dim3(grid), dim3(64), lds, stream, a, nw_max, static_cast<unsigned long long *>(claim), claim_mask);
+  hipLaunchKernelGGL(hg_confirm_huge_kernel, dim3(grid), dim3(64), lds, stream, a, nw_max, stage_cap, static_cast<unsigned long long *>(claim), claim_mask);
   return true;
 }
-bool hg_launch_always_on_huge(const HgConfirmArgs &a, uint32_t grid, uint32_t nw_max, uint32_t first, uint32_t last, hipStream_t stream) {
-  const size_t lds = hg_huge_lds_bytes(nw_max);
+bool hg_launch_always_on_huge(const HgConfirmArgs &a, uint32_t grid, uint32_t nw_max, uint32_t stage_cap, uint32_t first, uint32_t last, hipStream_t stream) {
+  const size_t lds = hg_huge_lds_bytes(nw_max, stage_cap);
   if (!allow_lds(hg_always_on_huge_kernel, lds)) return false;
-  hipLaunchKernelGGL(hg_always_on_huge_kernel, dim3(grid), dim3(64), lds, stream, a, nw_max, first, last);
+  hipLaunchKernelGGL(hg_always_on_huge_kernel, dim3(grid), dim3(64), lds, stream, a, nw_max, stage_cap, first, last);
   return true;
 }
-bool hg_launch_block_huge(const HgConfirmArgs &a, uint32_t grid, uint32_t nw_max, const uint32_t *pattern_flags, hipStream_t stream) {
-  const size_t lds = hg_huge_lds_bytes(nw_max);
+bool hg_launch_block_huge(const HgConfirmArgs &a, uint32_t grid, uint32_t nw_max, uint32_t stage_cap, const uint32_t *pattern_flags, hipStream_t stream) {
+  const size_t lds = hg_huge_lds_bytes(nw_max, stage_cap);
   if (!allow_lds(hg_block_huge_kernel, lds)) return false;
-  hipLaunchKernelGGL(hg_block_huge_kernel, dim3(grid), dim3(64), lds, stream, a, nw_max, pattern_flags);
+  hipLaunchKernelGGL(hg_block_huge_kernel, dim3(grid), dim3(64), lds, stream, a, nw_max, stage_cap, pattern_flags);
   return true;
 }

@@ -1084,6 +1084,68 @@ def test_config5_4096_literals_use_the_wide_filter(torch_cuda):
     del ctypes
 
 
+def test_config5_full_size_properties_32gib(torch_cuda):
+    """BASELINE config 5 at its per-GPU size (4096 literals, 10 % of the lines hit, 32 GiB in HBM): size-independent
+    properties — exact line count, strict (line, id, to) order, every report's `to` consistent with a 13-byte literal,
+    hit rate, idempotence — the head of the text against the oracle, and a window further in against Python `re`."""
+    import re_check
+    from hypergrep_amd import benchspec, device
+
+    torch = torch_cuda
+    free, _ = torch.cuda.mem_get_info()
+    if free < 90 << 30:
+        pytest.skip("needs 90 GiB of free HBM")
+    patterns, needles, hpm = benchspec.c5_spec()
+    ids = list(range(len(patterns)))
+    nbytes = 32 << 30
+    text = torch.empty(nbytes + 64, dtype=torch.uint8, device="cuda:0")
+    device.synth_device(text.data_ptr(), nbytes, benchspec.SEED_BASE + 5, needles, hpm)
+    torch.cuda.synchronize()
+    newlines = sum(int((text[o:min(o + (4 << 30), nbytes)] == 10).sum()) for o in range(0, nbytes, 4 << 30))
+    db = device.Database(patterns, ids=ids)
+    db.tune(b"".join(bytes(text[(i * (64 << 20)) & ~15: ((i * (64 << 20)) & ~15) + (256 << 10)].cpu().numpy()) for i in range(4)))
+    sc = device.Scanner(db, 0)
+
+    def run():
+        st = sc.scan(text.data_ptr(), nbytes)
+        buf = torch.empty((st.n_hits, 2), dtype=torch.int64, device="cuda:0")
+        assert sc.copy_hits_to(buf.data_ptr(), st.n_hits) == st.n_hits
+        torch.cuda.synchronize()
+        return st, buf
+
+    st, a = run()
+    assert st.n_lines == newlines + (0 if int(text[nbytes - 1]) == 10 else 1)
+    assert st.stream_launches == 4
+    line, rest = a[:, 0], a[:, 1]
+    ident, to = rest & 0xFFFFFFFF, (rest >> 32) & 0xFFFFFFFF
+    key = (ident << 32) | to
+    same_line = line[1:] == line[:-1]
+    assert bool(((line[1:] > line[:-1]) | (same_line & (key[1:] > key[:-1]))).all())
+    assert int(ident.max()) < 4096 and int(to.min()) >= 13  # a match ends at least a literal's length into its line
+    assert 0.09 < st.n_hits / st.n_lines < 0.11  # 10 % of the lines carry a needle
+    st2, b = run()
+    assert st2.n_hits == st.n_hits and bool((a == b).all())  # idempotent
+    del b
+    # the head against the oracle
+    head_n = 1 << 20
+    host = bytes(text[:head_n].cpu().numpy())
+    head_n = host.rfind(b"\n") + 1
+    want, nl = oracle_hits(host[:head_n], patterns, ids=ids)
+    n_head = int((line < nl).sum())
+    got = [(int(r[0]), int(r[1]) & 0xFFFFFFFF, int(r[1]) >> 32) for r in a[:n_head].cpu().tolist()]
+    assert got == [w[:3] for w in want]
+    # 8 MiB in the third pipeline chunk against Python re: the lines that begin in the window, by global line number
+    at = (20 << 30) + 12345
+    win = bytes(text[at: at + (8 << 20)].cpu().numpy())
+    first_nl = win.find(b"\n") + 1
+    win = win[first_nl: win.rfind(b"\n") + 1]
+    lines_before = sum(int((text[o:min(o + (4 << 30), at + first_nl)] == 10).sum()) for o in range(0, at + first_nl, 4 << 30))
+    want_pairs = {(ln + lines_before, i) for ln, i in re_check.literal_line_id_pairs(win, patterns)}
+    lo, hi = lines_before, lines_before + win.count(b"\n")
+    sel = a[(line >= lo) & (line < hi)].cpu().tolist()
+    assert {(int(r[0]), int(r[1]) & 0xFFFFFFFF) for r in sel} == want_pairs and len(want_pairs) > 5000
+
+
 def test_parallel_grep_with_worker_processes(torch_cuda, tmp_path, capsys):
     """The --mp path of the reference's CLI (hypergrep/multiscanner.py:197-198, 538-543: a multiprocessing.Pool instead of
     threads): here spawned workers, each initialising the GPU runtime itself.  Output equals the threaded run's."""

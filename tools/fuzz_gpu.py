@@ -42,6 +42,17 @@ def rich_pattern(rng):
     return "".join(parts)
 
 
+def huge_pattern(rng):
+    """Expressions beyond 1024 automaton positions (sparse tables, the wave-cooperative routine): bounded repeats over the
+    alphabet the random texts are made of, anchored or not by a literal, sometimes with boundary conditions."""
+    n = rng.choice([1030, 1100, 1500, 2100, 4000])
+    cls = rng.choice(["[a-c]", "[abcx01 ._-]", "[^y\\n]", ".", "[a-z0-9]", "(?:ab|c)"])
+    head = rng.choice(["", "x", "ab", "xyz_", "\\b", "^", "0="])
+    tail = rng.choice(["z", "y0", "_-", "$", "\\b", "1", " "])
+    lo = rng.choice([0, 1, n // 2, n])
+    return f"{head}{cls}{{{lo},{n}}}{tail}" if lo != n else f"{head}{cls}{{{n}}}{tail}"
+
+
 def regex_gen_escape(word):
     return "".join("\\" + c if c in ".-=" else c for c in word)
 
@@ -58,6 +69,7 @@ while time.time() - t0 < budget:
         with open(os.environ["HG_FUZZ_TRACE"], "a") as trace:
             trace.write(f"{seed - 1}\n")
     kind = rng.choice(["random", "random", "anchored", "mixed", "keywords", "keywords", "rich", "rich"])
+    with_huge = rng.random() < 0.06
     if kind == "keywords":  # word lists: byte-aligned probing, 3-byte windows, short and long literals side by side
         lo, hi = rng.choice([(3, 3), (3, 5), (4, 6), (3, 9), (5, 12)])
         n = rng.choice([2, 8, 40, 300])
@@ -79,6 +91,9 @@ while time.time() - t0 < budget:
         samplers = [s for _, s in pairs]
         if kind == "mixed":
             pats += [regex_gen.random_pattern(rng) for _ in range(rng.randint(1, 3))]
+    if with_huge:
+        pats = pats[:4] + [huge_pattern(rng) for _ in range(rng.randint(1, 2))]
+        samplers = samplers[:4]
     flags = [rng.choice([14, 14, 15, 10, 6, 12, 7, 2]) for _ in pats]
     ids = [rng.randint(0, 3) for _ in pats] if rng.random() < 0.7 else list(range(len(pats)))
     if oracle_py.check_patterns(pats, flags=flags) != 0:
@@ -89,12 +104,12 @@ while time.time() - t0 < budget:
             data += regex_gen.random_text(rng, 300, final_newline=rng.random() < 0.8)
     else:
         data = regex_gen.random_text(rng, rng.choice([40, 400, 3000]), maxlen=rng.choice([24, 24, 200]), final_newline=rng.random() < 0.8)
-    if rng.random() < 0.3:  # NULs and a very long line
+    if rng.random() < 0.3 or with_huge:  # NULs and a very long line
         b = bytearray(data)
         for _ in range(rng.randint(1, 8)):
             if b:
                 b[rng.randrange(len(b))] = 0
-        if rng.random() < 0.5:
+        if rng.random() < 0.5 or with_huge:
             at = rng.randrange(len(b) + 1)
             b[at:at] = bytes(rng.choice(b"abcx01 ._-") for _ in range(rng.choice([5000, 20000, 40000])))
         data = bytes(b)
