@@ -600,8 +600,11 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
           if (ca.mode_present[1] || ca.mode_present[2]) hipLaunchKernelGGL(hg_verify_kernel, dim3(verify_blocks), dim3(256), 0, side, ca);
           else hipLaunchKernelGGL(hg_verify_lean_kernel, dim3(verify_blocks), dim3(256), 0, side, ca);
           const bool literal_only_set = ca.mode_present[0] && !ca.mode_present[1] && !ca.mode_present[2];
-          if (literal_only_set) hipLaunchKernelGGL(hg_confirm_literal_kernel, dim3(mode_blocks), dim3(256), 0, side, ca);  // (blocks of 256: as many lanes per CU as before)
-          else if (fast_modes) hipLaunchKernelGGL(hg_confirm_fast_kernel, dim3(mode_blocks * fast_modes), dim3(HG_CONFIRM_THREADS), 0, side, ca, mode_blocks);
+          if (literal_only_set) {
+            hipLaunchKernelGGL(hg_confirm_literal_kernel, dim3(mode_blocks), dim3(256), 0, side, ca);  // (blocks of 256: as many lanes per CU as before)
+          } else if (fast_modes) {
+            hipLaunchKernelGGL(hg_confirm_fast_kernel, dim3(mode_blocks * fast_modes), dim3(HG_CONFIRM_THREADS), 0, side, ca, mode_blocks);
+          }
           if (db_->n_confirm_mode[3]) hipLaunchKernelGGL(hg_confirm_generic_kernel, dim3(mode_blocks), dim3(256), 0, side, ca);
           if (huge_blocks && ((mode_mask >> 4) & 1u)) {
             HG_TRY(hipMemsetAsync(d_huge_claim_, 0, huge_claim_slots_ * 8, side), "memset claim table");
