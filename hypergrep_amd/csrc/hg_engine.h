@@ -94,6 +94,9 @@ struct HgConfirmArgs {
   uint32_t always_list_cap;               // entries per block of the always-on match list (it reuses `deferred`)
   uint32_t list_spread[HG_CONFIRM_MODES];  // automaton modes: lists per pattern (few patterns: each is spread over several lists)
   uint32_t cand_seg_cap, hit_cap, hit_seg_cap, defer_shard_cap;
+  // Candidate segments [0, join_seg0) belong to the chunk's stream launch and hold cand_seg_cap records each; the segments from
+  // join_seg0 on belong to the joiner launch and hold join_seg_cap (a quarter: the joiner streams a few per cent of a chunk)
+  uint32_t join_seg0, join_seg_cap;
   uint32_t hit_direct;  // 1: a block whose staging segment is full appends to the compact array itself (HitSink)
   // Bucketed emission (the default, bucket_cap != 0): a hit goes straight into the region of the bucket its line starts in
   // (bucket = aux.start >> bucket_shift, bucket_cap records each, bucket_fill = records so far); the finalize kernels

@@ -492,7 +492,10 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       sa.seg_count = seg_count;
       const uint32_t joiners_c = c >= 1 ? joiner_wgs : 0u;
       const uint32_t segs_c = wgs_c + joiners_c;  // candidate segments of the chunk: one per stream workgroup
-      sa.cand_seg_cap = cand_cap_ / segs_c;
+      // (the joiner's segments get a quarter of a stream workgroup's: it streams a few per cent of a chunk, and equal shares took a
+      // third of the candidate workspace from the launch that fills it)
+      sa.cand_seg_cap = static_cast<uint32_t>(static_cast<uint64_t>(cand_cap_) * 4 / (4ull * wgs_c + joiners_c));
+      const uint32_t join_seg_cap = sa.cand_seg_cap / 4;
       sa.alone = (c == 0 && wgs_c == wgs_alone && !knobs_.stream_wgs_per_cu) ? 1u : 0u;
       sa.counters = d_counters_;
       HG_TRY(hipEventRecord(piped ? ev_k1_begin_[c] : ev_[1], stream), "event");
@@ -518,6 +521,7 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       if (joiners_c) {  // (the side stream: behind the side passes of chunk c - 1, in front of those of chunk c)
         HgStreamArgs ja = sa;
         ja.cands = cands + static_cast<uint64_t>(wgs_c) * sa.cand_seg_cap;
+        ja.cand_seg_cap = join_seg_cap;
         ja.seg_count = seg_count + wgs_c;
         ja.alone = 0;
         if (!hg_launch_stream_join(ja, joiners_c, side)) return HG_ERR_ARG;
@@ -542,6 +546,8 @@ int HgScanner::run_once(const uint8_t *text, uint64_t nbytes, uint64_t bs1, uint
       ca.tmp_hits = d_hits_out_;  // free until the final select
       ca.tmp_aux = d_aux_out_;
       ca.cand_seg_cap = sa.cand_seg_cap;
+      ca.join_seg0 = wgs_c;
+      ca.join_seg_cap = join_seg_cap;
       ca.hit_cap = hit_cap_;
       ca.hit_direct = hit_direct_ ? 1u : 0u;
       ca.bucket_cap = bucketed ? fin_cap : 0u;

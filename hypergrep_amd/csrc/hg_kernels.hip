@@ -926,9 +926,12 @@ __device__ __forceinline__ void verify_body(const HgConfirmArgs &a, VerifyStage 
   uint32_t pf_rounds = 0, pf_pairs = 0;
 #endif
   const uint32_t seg = blockIdx.x / HG_CONFIRM_SPLIT, sub = blockIdx.x % HG_CONFIRM_SPLIT;
-  const HgCand *cseg = a.cands + static_cast<uint64_t>(seg) * a.cand_seg_cap;
+  const bool joined = seg >= a.join_seg0;  // a segment of the joiner launch (smaller)
+  const uint32_t seg_cap = joined ? a.join_seg_cap : a.cand_seg_cap;
+  const HgCand *cseg = joined ? a.cands + static_cast<uint64_t>(a.join_seg0) * a.cand_seg_cap + static_cast<uint64_t>(seg - a.join_seg0) * a.join_seg_cap
+                              : a.cands + static_cast<uint64_t>(seg) * a.cand_seg_cap;
   uint32_t n = a.seg_count[seg];
-  if (n > a.cand_seg_cap) n = a.cand_seg_cap;  // (never more than a segment holds, whatever the counter says)
+  if (n > seg_cap) n = seg_cap;  // (never more than a segment holds, whatever the counter says)
   const uint32_t shard = blockIdx.x % HG_DEFER_SHARDS;
   const uint32_t fold = a.db.fold_mask;
   const uint64_t readable = (a.nbytes + 15) & ~15ull;  // the text buffer can be read up to here
