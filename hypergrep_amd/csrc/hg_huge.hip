@@ -21,6 +21,8 @@
 // Byte/integer work, no MFMA.  Wave64 only; workgroups are ONE wave.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "hg_core.h"
 #include "hg_engine.h"
 #include "hg_sink_dev.h"
@@ -497,24 +499,31 @@ bool allow_lds(K kernel, size_t bytes) {
 
 }  // namespace
 
-// LDS of a huge-automaton workgroup: two copies of the largest automaton's state words + the staged tables.
-size_t hg_huge_lds_bytes(uint32_t nw_max, uint32_t stage_cap) { return (static_cast<size_t>(nw_max) * 2u + stage_cap) * 4u; }
+// LDS of a huge-automaton workgroup: two copies of the largest automaton's state words + the staged tables.  A workgroup may take
+// the whole 160 KiB of a CU: the staging area shrinks to what the state words leave (an expression whose tables then do not fit
+// reads them from L2).
+static uint32_t clamp_stage(uint32_t nw_max, uint32_t stage_cap) {
+  const size_t room = (160u * 1024u - 256u) / 4u;  // words; a little is kept for the kernels' static LDS
+  const size_t state = static_cast<size_t>(nw_max) * 2u;
+  return static_cast<uint32_t>(state >= room ? 0u : std::min<size_t>(stage_cap, room - state));
+}
+size_t hg_huge_lds_bytes(uint32_t nw_max, uint32_t stage_cap) { return (static_cast<size_t>(nw_max) * 2u + clamp_stage(nw_max, stage_cap)) * 4u; }
 
 bool hg_launch_confirm_huge(const HgConfirmArgs &a, uint32_t grid, uint32_t nw_max, uint32_t stage_cap, void *claim, uint32_t claim_mask, hipStream_t stream) {
   const size_t lds = hg_huge_lds_bytes(nw_max, stage_cap);
   if (!allow_lds(hg_confirm_huge_kernel, lds)) return false;
-  hipLaunchKernelGGL(hg_confirm_huge_kernel, dim3(grid), dim3(64), lds, stream, a, nw_max, stage_cap, static_cast<unsigned long long *>(claim), claim_mask);
+  hipLaunchKernelGGL(hg_confirm_huge_kernel, dim3(grid), dim3(64), lds, stream, a, nw_max, clamp_stage(nw_max, stage_cap), static_cast<unsigned long long *>(claim), claim_mask);
   return true;
 }
 bool hg_launch_always_on_huge(const HgConfirmArgs &a, uint32_t grid, uint32_t nw_max, uint32_t stage_cap, uint32_t first, uint32_t last, hipStream_t stream) {
   const size_t lds = hg_huge_lds_bytes(nw_max, stage_cap);
   if (!allow_lds(hg_always_on_huge_kernel, lds)) return false;
-  hipLaunchKernelGGL(hg_always_on_huge_kernel, dim3(grid), dim3(64), lds, stream, a, nw_max, stage_cap, first, last);
+  hipLaunchKernelGGL(hg_always_on_huge_kernel, dim3(grid), dim3(64), lds, stream, a, nw_max, clamp_stage(nw_max, stage_cap), first, last);
   return true;
 }
 bool hg_launch_block_huge(const HgConfirmArgs &a, uint32_t grid, uint32_t nw_max, uint32_t stage_cap, const uint32_t *pattern_flags, hipStream_t stream) {
   const size_t lds = hg_huge_lds_bytes(nw_max, stage_cap);
   if (!allow_lds(hg_block_huge_kernel, lds)) return false;
-  hipLaunchKernelGGL(hg_block_huge_kernel, dim3(grid), dim3(64), lds, stream, a, nw_max, stage_cap, pattern_flags);
+  hipLaunchKernelGGL(hg_block_huge_kernel, dim3(grid), dim3(64), lds, stream, a, nw_max, clamp_stage(nw_max, stage_cap), pattern_flags);
   return true;
 }

@@ -152,6 +152,18 @@ def run_huge() -> dict:
                     bad.append({"case": f"buffer-{ci}-{seed}-{bs}", "patterns": pats, "got": len(got), "want": len(want), "lines": [stats.n_lines, nlines],
                                 "extra": sorted(set(got) - set(want))[:6], "missing": sorted(set(want) - set(got))[:6]})
                 n += 1
+    # the largest automaton the compiler takes (393 204 positions: 12 288 state words, 96 KiB of LDS for the two state copies) beside
+    # a small huge one (staged tables, the register-resident routine), on text where the monster's state stays small
+    monster = "a{32767}" * 12
+    big = [monster, "foo.{0,3000}bar", "a{3}b"]
+    text = case_text("dotfoo", 7) + b"\n" + b"a" * 5000 + b"b\n" + b"aaab foo" + b"a" * 100 + b"bar\n"
+    want, nlines = oracle_hits(text, big, None, [0, 1, 2])
+    db = device.Database(big, ids=[0, 1, 2])
+    sc = device.Scanner(db, 0)
+    stats = sc.scan(arena.place(text), len(text))
+    if sorted(sc.hits()) != want or stats.n_lines != nlines:
+        bad.append({"case": "monster", "got": stats.n_hits, "want": len(want)})
+    n += 1
     # a huge expression among ordinary ones of every confirm mode, shared ids; then through the file API (batches, line bytes)
     mixed = ["foo.{0,3000}bar", "needle_in_haystack", "fo+bar[0-9]", "\\bq[a-z]{1100,1300}\\b", "^[a-z]+ [a-z0-9 =._-]+$", "[a-z]{2000}x", "thread"]
     mflags = [14, 14, 14, 14, 14, 6, 14]
