@@ -347,7 +347,10 @@ __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, 
     const uint64_t g = chunk0 + static_cast<uint64_t>(it) * 64u;
     if (FULL) {
       // streaming (non-temporal) cache policy: the text is read once and must not push the filter's second level, the
-      // tile summaries and the side passes' working set out of the L2 (measured: 5.0 -> 5.4 TB/s in the pipeline)
+      // tile summaries and the side passes' working set out of the L2 (measured: 5.0 -> 5.4 TB/s in the pipeline).
+      // Not for wide filters: their drain reads every queued chunk AGAIN a few microseconds later (no room in LDS to carry
+      // it in the queue), and with the default policy most of those reads hit the L2 (config 5: 14.98 -> 14.65 ms per 32 GiB)
+      if (WIDE) return text16[g];
 #if defined(HG_NO_NT_LOADS)
       return text16[g];
 #else
