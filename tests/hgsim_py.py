@@ -74,10 +74,10 @@ class Db:
 
     def selfcheck(self) -> dict:
         """Table invariants (hostsim.cpp::hgsim_selfcheck): violations must be 0."""
-        out = (ctypes.c_uint32 * 5)()
+        out = (ctypes.c_uint32 * 6)()
         lib().hgsim_selfcheck.restype = ctypes.c_uint32
         bad = lib().hgsim_selfcheck(ctypes.c_void_p(self.h), out)
-        return {"violations": bad, "filter_log2": out[0], "wide": out[1], "crowded_slots": out[2], "byte_windows": out[3], "shared_windows": out[4]}
+        return {"violations": bad, "filter_log2": out[0], "wide": out[1], "crowded_slots": out[2], "byte_windows": out[3], "shared_windows": out[4], "table_first": out[5]}
 
     def tune(self, sample: bytes) -> int:
         lib().hgsim_tune.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]

@@ -62,7 +62,7 @@ static HgDbView view_of(HgDb *db);
 //  (1) passes the first level at its own slot, (2) passes the second level when the literal's own bytes surround it,
 //  (3) is found by the verify pass's discriminated bucket lookup when the literal itself is the text.
 // Returns the number of violations; out[0] = filter log2, out[1] = wide, out[2] = slots holding more than two values.
-uint32_t hgsim_selfcheck(void *h, uint32_t *out) {  // out[5]
+uint32_t hgsim_selfcheck(void *h, uint32_t *out) {  // out[6]
   HgDb *db = static_cast<HgDb *>(h);
   const HgDbView v = view_of(db);
   uint32_t bad = 0, many = 0;
@@ -119,7 +119,7 @@ uint32_t hgsim_selfcheck(void *h, uint32_t *out) {  // out[5]
       if (k && b.factor_off[k] != HG_WTAB_EMPTY && b.factor_off[k - 1] == HG_WTAB_EMPTY) bad++;
     }
   if (used * 2 > db->wtab.size() * HG_WTAB_WAYS || db->wtab.size() != static_cast<size_t>(db->wtab_mask) + 1) bad++;
-  if (out) out[4] = db->shared_windows;
+  if (out) { out[4] = db->shared_windows; out[5] = db->wtab_first; }
   return bad;
 }
 uint32_t hgsim_pattern_tier(void *h, uint32_t i) { return static_cast<HgDb *>(h)->patterns[i].tier; }

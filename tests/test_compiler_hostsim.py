@@ -436,3 +436,21 @@ def test_end_offsets_against_python_re(seed):
         assert [(h[0], h[2]) for h in got1] == sorted(first.items()), (pat, flags, data)
         nonempty += bool(want)
     assert nonempty >= 2
+
+
+def test_direct_window_table_on_the_benchmark_sets():
+    """Round 3's direct window table (hg_db.h HgWinBucket): every window of every literal is found in it (selfcheck invariant 4),
+    config 5's K%04x-%08x literals get single-owner windows (the selection avoids the `xxx-` windows sixteen literals share) and
+    the verify pass asks the table first there; config 3's class expressions share their stems: the discriminated buckets first."""
+    from hypergrep_amd import benchspec, device
+
+    for name, first, most_shared in (("c5", 1, 400), ("c3", 0, 400), ("c1", 1, 0)):
+        pats, needles, hpm = getattr(benchspec, name + "_spec")()
+        db = hgsim_py.Db(pats, None, list(range(len(pats))))
+        assert db.ok(), db.error
+        check = db.selfcheck()
+        assert check["violations"] == 0 and check["table_first"] == first and check["shared_windows"] <= most_shared, (name, check)
+        sample = device.synth_host(1 << 20, benchspec.SEED_BASE + int(name[1]), needles, hpm)
+        assert db.tune(sample) == 0
+        tuned = db.selfcheck()
+        assert tuned["violations"] == 0 and tuned["table_first"] == first, (name, tuned)
