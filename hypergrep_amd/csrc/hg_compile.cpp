@@ -1014,6 +1014,19 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
     mine.erase(std::unique(mine.begin(), mine.end()), mine.end());
     for (uint32_t v : mine) contenders[v]++;
   }
+  // the case variants of the window at offset o of a literal: all of them when nothing is folded (fold == 0), else the one folded value
+  auto variants = [&](const HgFactor &fct, uint32_t o, std::vector<uint32_t> &out) {
+    uint32_t v = 0;
+    std::memcpy(&v, fct.lit + o, wbytes);
+    out.assign(1, (v | fold) & wmask);
+    if (fold) return;
+    for (uint32_t b = 0; b < wbytes; b++)
+      if ((fct.casebits >> (o + b)) & 1u) {  // a case-insensitive letter (stored in lower case): both cases
+        const size_t have = out.size();
+        for (size_t i = 0; i < have; i++) out.push_back(out[i] ^ (0x20u << (8 * b)));
+      }
+  };
+  std::vector<uint32_t> vars;
   for (uint32_t fi = 0; fi < db.nreal_factors; fi++) {
     const HgFactor &fct = db.factors[fi];
     Lit l{std::string(reinterpret_cast<const char *>(fct.lit), fct.len), std::string(fct.len, '\xFF')};
@@ -1052,9 +1065,12 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
         std::memcpy(&v, fct.lit + o, wbytes);
         v = (v | fold) & wmask;
         long cost = 0;
-        if (stats) {  // the hot path compares the window dword alone: its frequency in the sample is what costs
-          auto it = stats->c4.find(v);
-          cost = it == stats->c4.end() ? 0 : it->second;
+        if (stats) {  // the hot path compares the window dword alone: its frequency in the sample is what costs (all case variants)
+          variants(fct, o, vars);
+          for (uint32_t x : vars) {
+            auto it = stats->c4.find(x);
+            cost += it == stats->c4.end() ? 0 : it->second;
+          }
         }
         const uint32_t shared = contenders[v] > 1 ? contenders[v] : 0;
         int sel = 0;
@@ -1069,11 +1085,13 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
         }
       }
       if (best < 0) continue;  // cannot happen for len >= HG_FAST_MIN_FACTOR
-      uint32_t v = 0;
-      std::memcpy(&v, fct.lit + best, wbytes);
-      v = (v | fold) & wmask;  // case-insensitive positions hold lower-case letters already; folding maps both cases onto them
-      keyed.push_back({hg_hash_window(v), HgWindow{v, (fi << 8) | static_cast<uint32_t>(best)}});
-      next16_of.push_back(0);
+      // (case-insensitive positions hold lower-case letters already: folding maps both cases onto them; without folding every
+      // case variant of the window is a window of its own)
+      variants(fct, static_cast<uint32_t>(best), vars);
+      for (uint32_t x : vars) {
+        keyed.push_back({hg_hash_window(x), HgWindow{x, (fi << 8) | static_cast<uint32_t>(best)}});
+        next16_of.push_back(0);
+      }
     }
   }
   {  // sort by bucket, carrying next16 along
@@ -1120,8 +1138,10 @@ int build_filter(HgDb &db, const SampleStats *stats, std::string *err) {
           for (size_t e = g0; e < g1; e++) {
             const HgFactor &fct = db.factors[keyed[e].second.factor_off >> 8];
             const int at = static_cast<int>(keyed[e].second.factor_off & 0xff) + delta;
-            for (int b = 0; b < 4; b++)
+            for (int b = 0; b < 4; b++) {
               if (at + b < 0 || at + b >= static_cast<int>(fct.len)) sel &= ~(1u << b);
+              else if (!fold && hg_factor_cmask(fct, at + b) != 0xFF) sel &= ~(1u << b);  // (nothing is folded: a case-insensitive letter discriminates nothing)
+            }
           }
           if (!sel) continue;
           std::vector<uint32_t> ks;
@@ -1378,6 +1398,7 @@ struct CompileKnobs {
   bool no_ctx_groups = std::getenv("HG_NO_CTX_GROUPS") != nullptr;
   bool no_confirm_window = std::getenv("HG_NO_CONFIRM_WINDOW") != nullptr;
   bool no_byte_windows = std::getenv("HG_NO_BYTE_WINDOWS") != nullptr;
+  bool no_case_expand = std::getenv("HG_NO_CASE_EXPAND") != nullptr;
 };
 
 void build_slow_groups(HgDb &db, const CompileKnobs &knobs) {
@@ -1730,6 +1751,7 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
     db->slow.clear();
     db->factors.clear();
     db->fold_mask = 0;
+    size_t nlits = 0, ncaseless = 0;  // required literals of the anchored expressions / those with case-insensitive letters
     for (uint32_t m = 0; m < HG_CONFIRM_MODES; m++) db->n_confirm_mode[m] = 0;
     for (unsigned i = 0; i < n; i++) {
       HgPattern &p = db->patterns[i];
@@ -1739,12 +1761,24 @@ int hgc_compile(const char *const *exprs, const unsigned *flags, const unsigned 
       p.literal_only = (fast && covers[i].literal_only) ? 1 : 0;
       if (fast) {
         db->n_confirm_mode[hg_confirm_mode(p)]++;
-        for (auto &l : cover)
-          for (unsigned char m : l.cmask)
-            if (m != 0xFF) db->fold_mask = 0x20202020u;
+        for (auto &l : cover) {
+          nlits++;
+          bool caseless = false;
+          for (unsigned char m : l.cmask) caseless = caseless || m != 0xFF;
+          ncaseless += caseless ? 1 : 0;
+        }
       } else {
         db->slow.push_back(i);
       }
+    }
+    // Case-insensitive literals.  The general way: the stream pass folds every text dword (| 0x20202020) before it hashes it, and the
+    // windows are stored folded.  Where only a few literals of a set of dword-aligned windows are case-insensitive, their windows are
+    // stored in every case variant instead (at most 16 per window) and NOTHING is folded: the hot loop saves an instruction per
+    // dword, and folded look-alikes ('@' / '`', '[' / '{', upper-case text) no longer pass the filter.
+    if (ncaseless) {
+      const bool expand = !dense && !knobs.no_case_expand && ncaseless <= 64;  // (at most 64 x 4 windows x 16 variants more)
+      (void)nlits;
+      db->fold_mask = expand ? 0u : 0x20202020u;
     }
     // always-on patterns of at most two state words go first: the segment-parallel kernel takes those
     auto two_words = [&](uint32_t pi) { return db->patterns[pi].nw <= 2; };  // bounded or not: an unbounded pattern's lead-in is the start of its line

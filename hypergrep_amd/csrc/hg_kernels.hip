@@ -75,9 +75,11 @@ struct Probe {
   }
   // First level for the lane's four dwords: a slot matches if it holds the window's hash C.
   // ANY_ONLY: non-zero iff any of the four windows matched (hot path); else per-window, per-slot match bits.
-  template <bool ANY_ONLY>
+  // FOLD: the set folds the text before hashing it (case-insensitive literals stored folded); false: nothing is folded (no such
+  // literal, or their windows are stored in every case variant): one instruction per dword less in the hot loop
+  template <bool ANY_ONLY, bool FOLD = true>
   __device__ __forceinline__ static uint32_t probe4(const lds_u32 *filter, uint32_t fold, uint32_t wa, uint32_t wb, uint4 v) {
-    const uint32_t f0 = v.x | fold, f1 = v.y | fold, f2 = v.z | fold, f3 = v.w | fold;
+    const uint32_t f0 = FOLD ? v.x | fold : v.x, f1 = FOLD ? v.y | fold : v.y, f2 = FOLD ? v.z | fold : v.z, f3 = FOLD ? v.w | fold : v.w;
     // the hashes of the four windows first (independent v_dot4), then the eight LDS reads
     const uint32_t a0 = hg_dot4(f0, wa), a1 = hg_dot4(f1, wa), a2 = hg_dot4(f2, wa), a3 = hg_dot4(f3, wa);
     const uint32_t b0 = hg_dot4(f0, wb), b1 = hg_dot4(f1, wb), b2 = hg_dot4(f2, wb), b3 = hg_dot4(f3, wb);
@@ -337,7 +339,7 @@ __device__ __noinline__ void drain_batch(const StreamCtx cx, uint32_t first, uin
 
 // One tile.  FULL: the tile lies entirely inside the text (no bounds checks on the hot path).
 // qn: entries in the wave's queue (wave-uniform, carried from tile to tile).
-template <int LOG2, bool WIDE, int DENSE, bool FULL, int DEPTH>
+template <int LOG2, bool WIDE, int DENSE, bool FULL, int DEPTH, bool FOLD>
 __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, HgTileSum *__restrict__ sums, uint32_t lane, uint32_t &qn) {
   const uint4 *__restrict__ text16 = cx.text16;
   const uint64_t nbytes = cx.nbytes;
@@ -392,7 +394,7 @@ __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, 
       const uint32_t nxt = __builtin_amdgcn_update_dpp(after, cur.x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);  // lane 63 keeps `after`
       any = ProbeBytes<LOG2, DENSE ? DENSE : 1>::template probe16<true>(cx.filter, cx.fold, cx.wa, cx.wb, cur, nxt) != 0;
     } else {
-      any = Probe<LOG2, WIDE>::template probe4<true>(cx.filter, cx.fold, cx.wa, cx.wb, cur) != 0;
+      any = Probe<LOG2, WIDE>::template probe4<true, FOLD>(cx.filter, cx.fold, cx.wa, cx.wb, cur) != 0;
     }
 #endif
 
@@ -513,7 +515,7 @@ __device__ __forceinline__ void stream_tile(const StreamCtx &cx, uint64_t tile, 
 // that had three workgroups per CU to itself did better with one: deeper prefetch thrashed the L2).
 // JOIN: the launch that joins a chunk behind the previous chunk's side passes (hg_stream_join_kernel, same code under its
 // own name so that profiles keep the two kinds of launch apart); it also counts the tiles it took (HG_CNT_JOIN_TILES).
-template <int LOG2, bool WIDE, int DENSE, int DEPTH, bool JOIN>
+template <int LOG2, bool WIDE, int DENSE, int DEPTH, bool JOIN, bool FOLD>
 __device__ __forceinline__ void stream_body(const uint4 *__restrict__ text16, uint64_t nbytes, uint64_t tile_begin, uint64_t tile_end, const uint4 *__restrict__ filter16,
                                             const uint4 *__restrict__ ext16, uint32_t fold, uint32_t wa, uint32_t wb, HgTileSum *__restrict__ sums, HgCand *__restrict__ cands,
                                             uint32_t seg_cap, uint32_t *__restrict__ seg_count, uint32_t *__restrict__ counters, uint32_t cursor_slot) {
@@ -560,8 +562,8 @@ __device__ __forceinline__ void stream_body(const uint4 *__restrict__ text16, ui
     const uint32_t r1 = r0 + HG_STREAM_GRAB < ntile ? r0 + HG_STREAM_GRAB : ntile;
     if (JOIN) joined += r1 - r0;
     for (uint32_t r = r0 + wave; r < r1; r += WG_WAVES) {
-      if (r < nfull) stream_tile<LOG2, WIDE, DENSE, true, DEPTH>(cx, tile_begin + r, sums, lane, qn);
-      else stream_tile<LOG2, WIDE, DENSE, false, DEPTH>(cx, tile_begin + r, sums, lane, qn);
+      if (r < nfull) stream_tile<LOG2, WIDE, DENSE, true, DEPTH, FOLD>(cx, tile_begin + r, sums, lane, qn);
+      else stream_tile<LOG2, WIDE, DENSE, false, DEPTH, FOLD>(cx, tile_begin + r, sums, lane, qn);
     }
   }
   if (qn) drain_batch<LOG2, WIDE, DENSE>(cx, 0u, qn, lane);
@@ -574,19 +576,19 @@ __device__ __forceinline__ void stream_body(const uint4 *__restrict__ text16, ui
     if (JOIN && joined) atomicAdd(&counters[HG_CNT_JOIN_TILES], joined);
   }
 }
-template <int LOG2, bool WIDE, int DENSE, int DEPTH>
+template <int LOG2, bool WIDE, int DENSE, int DEPTH, bool FOLD = true>
 __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_STREAM_WAVES, 8))) void hg_stream_kernel(
     const uint4 *__restrict__ text16, uint64_t nbytes, uint64_t tile_begin, uint64_t tile_end, const uint4 *__restrict__ filter16, const uint4 *__restrict__ ext16, uint32_t fold,
     uint32_t wa, uint32_t wb, HgTileSum *__restrict__ sums, HgCand *__restrict__ cands, uint32_t seg_cap, uint32_t *__restrict__ seg_count, uint32_t *__restrict__ counters,
     uint32_t cursor_slot) {
-  stream_body<LOG2, WIDE, DENSE, DEPTH, false>(text16, nbytes, tile_begin, tile_end, filter16, ext16, fold, wa, wb, sums, cands, seg_cap, seg_count, counters, cursor_slot);
+  stream_body<LOG2, WIDE, DENSE, DEPTH, false, FOLD>(text16, nbytes, tile_begin, tile_end, filter16, ext16, fold, wa, wb, sums, cands, seg_cap, seg_count, counters, cursor_slot);
 }
-template <int LOG2, int DENSE>  // (only where three workgroups fit on a CU: filters of up to 32 KiB, single-probe mode)
+template <int LOG2, int DENSE, bool FOLD = true>  // (only where three workgroups fit on a CU: filters of up to 32 KiB, single-probe mode)
 __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_STREAM_WAVES, 8))) void hg_stream_join_kernel(
     const uint4 *__restrict__ text16, uint64_t nbytes, uint64_t tile_begin, uint64_t tile_end, const uint4 *__restrict__ filter16, const uint4 *__restrict__ ext16, uint32_t fold,
     uint32_t wa, uint32_t wb, HgTileSum *__restrict__ sums, HgCand *__restrict__ cands, uint32_t seg_cap, uint32_t *__restrict__ seg_count, uint32_t *__restrict__ counters,
     uint32_t cursor_slot) {
-  stream_body<LOG2, false, DENSE, HG_DEPTH_SHARED, true>(text16, nbytes, tile_begin, tile_end, filter16, ext16, fold, wa, wb, sums, cands, seg_cap, seg_count, counters, cursor_slot);
+  stream_body<LOG2, false, DENSE, HG_DEPTH_SHARED, true, FOLD>(text16, nbytes, tile_begin, tile_end, filter16, ext16, fold, wa, wb, sums, cands, seg_cap, seg_count, counters, cursor_slot);
 }
 
 // Host-side launcher: picks the instantiation for the database's filter size / mode.
@@ -596,7 +598,15 @@ void launch_depth(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
   const uint4 *t = reinterpret_cast<const uint4 *>(a.text);
   const uint4 *f = reinterpret_cast<const uint4 *>(a.filter);
   const uint4 *x = reinterpret_cast<const uint4 *>(a.ext);
-  hipLaunchKernelGGL((hg_stream_kernel<L, W, B, D>), dim3(grid), dim3(WG_THREADS), 0, stream, t, a.nbytes, a.tile_begin, a.tile_end, f, x, a.db.fold_mask,
+  // (dword-aligned single-probe filters of sets that fold nothing: the variant without the fold instruction)
+  if constexpr (!W && !B) {
+    if (a.db.fold_mask == 0) {
+      hipLaunchKernelGGL((hg_stream_kernel<L, W, B, D, false>), dim3(grid), dim3(WG_THREADS), 0, stream, t, a.nbytes, a.tile_begin, a.tile_end, f, x, a.db.fold_mask,
+                         a.weights_a, a.dense ? a.weights_c : a.weights_b, a.sums, a.cands, a.cand_seg_cap, a.seg_count, a.counters, a.cursor_slot);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((hg_stream_kernel<L, W, B, D, true>), dim3(grid), dim3(WG_THREADS), 0, stream, t, a.nbytes, a.tile_begin, a.tile_end, f, x, a.db.fold_mask,
                      a.weights_a, a.dense ? a.weights_c : a.weights_b, a.sums, a.cands, a.cand_seg_cap, a.seg_count, a.counters, a.cursor_slot);
 }
 template <int L, bool W, int B>
@@ -616,7 +626,15 @@ int blocks_one() {
 namespace {
 template <int L, int B>
 void launch_join(const HgStreamArgs &a, uint32_t grid, hipStream_t stream) {
-  hipLaunchKernelGGL((hg_stream_join_kernel<L, B>), dim3(grid), dim3(WG_THREADS), 0, stream, reinterpret_cast<const uint4 *>(a.text), a.nbytes, a.tile_begin, a.tile_end,
+  if constexpr (B == 0) {
+    if (a.db.fold_mask == 0) {
+      hipLaunchKernelGGL((hg_stream_join_kernel<L, B, false>), dim3(grid), dim3(WG_THREADS), 0, stream, reinterpret_cast<const uint4 *>(a.text), a.nbytes, a.tile_begin, a.tile_end,
+                         reinterpret_cast<const uint4 *>(a.filter), reinterpret_cast<const uint4 *>(a.ext), a.db.fold_mask, a.weights_a, a.dense ? a.weights_c : a.weights_b, a.sums,
+                         a.cands, a.cand_seg_cap, a.seg_count, a.counters, a.cursor_slot);
+      return;
+    }
+  }
+  hipLaunchKernelGGL((hg_stream_join_kernel<L, B, true>), dim3(grid), dim3(WG_THREADS), 0, stream, reinterpret_cast<const uint4 *>(a.text), a.nbytes, a.tile_begin, a.tile_end,
                      reinterpret_cast<const uint4 *>(a.filter), reinterpret_cast<const uint4 *>(a.ext), a.db.fold_mask, a.weights_a, a.dense ? a.weights_c : a.weights_b, a.sums,
                      a.cands, a.cand_seg_cap, a.seg_count, a.counters, a.cursor_slot);
 }
@@ -892,9 +910,9 @@ __device__ __forceinline__ uint32_t wtab_lookup(const HgWinBucket *tab, uint32_t
 }
 // Does the literal of `f` (len bytes, HgFactor) occur at text[fs, fs + len)?  The record is one cache line: the literal as
 // 16-byte pieces, the compare masks from its case bits; the text unaligned.  fs + len <= nbytes.
-__device__ __forceinline__ bool literal_occurs(const HgFactor *f, uint32_t len, const uint8_t *text, uint64_t fs, uint64_t readable, bool folding) {
+__device__ __forceinline__ bool literal_occurs(const HgFactor *f, uint32_t len, const uint8_t *text, uint64_t fs, uint64_t readable) {
   const uint8_t *tp = text + fs;
-  const uint32_t cb = folding ? f->casebits : 0u;
+  const uint32_t cb = f->casebits;  // (zero for an exact literal; a set may hold case-insensitive literals without folding its windows)
   uint32_t diff = 0;
   if (fs + (len > 16 ? 32u : 16u) <= readable) {
     const uint4 l0 = *reinterpret_cast<const uint4 *>(f->lit);
@@ -1031,7 +1049,7 @@ __device__ __forceinline__ void verify_body(const HgConfirmArgs &a, VerifyStage 
           const uint32_t len = hdr.y;
           if (pos >= off && pos - off + len <= a.nbytes) {
             const uint64_t fs = pos - off;
-            const uint32_t diff = literal_occurs(f, len, a.text, fs, readable, fold != 0) ? 0u : 1u;
+            const uint32_t diff = literal_occurs(f, len, a.text, fs, readable) ? 0u : 1u;
             if (diff == 0) {
               ok = true;
               mode = hdr.z;

@@ -53,8 +53,9 @@ def test_tiers_and_factors():
     assert db.ok(), db.error
     assert [db.tier(i) for i in range(5)] == [0, 0, 1, 0, 0]
     info = db.info()
-    assert info["nslow"] == 1 and info["fold_mask"] == 0x20202020
-    assert info["nfactors"] >= 5 and info["nwindows"] == 4 * info["nfactors"]
+    # one case-insensitive literal among five: its windows are stored in every case variant and nothing is folded (round 3)
+    assert info["nslow"] == 1 and info["fold_mask"] == 0
+    assert info["nfactors"] >= 5 and 4 * info["nfactors"] < info["nwindows"] <= 4 * (info["nfactors"] - 1) + 4 * 16
     assert db.selfcheck()["byte_windows"] == 0
     # a 6-byte literal joins: the whole set switches to byte-aligned probing; every literal has >= 5 bytes, so a window
     # starts at every SECOND byte and each literal gets one window per residue mod 2
@@ -454,3 +455,42 @@ def test_direct_window_table_on_the_benchmark_sets():
         assert db.tune(sample) == 0
         tuned = db.selfcheck()
         assert tuned["violations"] == 0 and tuned["table_first"] == first, (name, tuned)
+
+
+def test_case_insensitive_literals_as_case_variants_or_folded(monkeypatch):
+    """A set with a few case-insensitive literals stores their windows in every case variant and folds nothing (round 3); with many
+    (or with HG_NO_CASE_EXPAND) the text is folded as before.  Same reports either way, equal to the oracle's, on text with every
+    mix of cases, look-alikes that only differ by the fold bit ('@' / '`', '[' / '{') and discriminated window groups."""
+    rng = random.Random(11)
+    pats = ["(?i)Unhandled_Exception_9: [a-z]+error", "needle_in_haystack", "(?i)tls_handshake_failed", "status=5[0-9]{2} retry",
+            "(?i)status=4[0-9]{2} GIVE_UP", "(?i)abc@def\\[xyz", "plain_literal_{x}"]
+    flags = [14, 14, 14, 14, 15, 14, 14]
+    ids = list(range(len(pats)))
+    samples = [b"Unhandled_Exception_9: fooerror", b"UNHANDLED_exception_9: barERROR", b"unhandled_exception_9: xerror", b"Unhandled_Exception_8: fooerror",
+               b"TLS_HANDSHAKE_FAILED", b"tls_Handshake_Failed", b"tls_handshake_failex", b"needle_in_haystack", b"NEEDLE_IN_HAYSTACK", b"status=503 retry",
+               b"STATUS=503 retry", b"status=404 give_up", b"Status=404 GIVE_UP", b"ABC@DEF[XYZ", b"abc`def{xyz", b"abc@def[xyz", b"plain_literal_{x}", b"plain_literal_[x]"]
+    lines = []
+    for _ in range(1500):
+        line = bytearray()
+        for _ in range(rng.randint(0, 4)):
+            line += rng.choice(samples) if rng.random() < 0.5 else bytes(rng.choice(b"abcXYZ_ =@`[{19") for _ in range(rng.randint(1, 12)))
+            line += b" "
+        lines.append(bytes(line))
+    data = b"\n".join(lines) + b"\n"
+    want, nlines = oracle_hits(data, pats, flags, ids)
+    assert len(want) > 300
+    for knob, fold in ((None, 0), ("1", 0x20202020)):
+        if knob:
+            monkeypatch.setenv("HG_NO_CASE_EXPAND", knob)
+        db = hgsim_py.Db(pats, flags, ids)
+        assert db.ok(), db.error
+        assert db.info()["fold_mask"] == fold and db.selfcheck()["violations"] == 0
+        got, stats = db.scan(data)
+        assert sorted(got) == want and stats["pieces"] == nlines, knob
+        assert db.tune(data[:40000]) == 0 and db.selfcheck()["violations"] == 0
+        got, _ = db.scan(data)
+        assert sorted(got) == want, (knob, "tuned")
+    # more than 64 case-insensitive literals: folding
+    many = [f"(?i)Keyword_{i:03d}_Tail" for i in range(70)]
+    db = hgsim_py.Db(many)
+    assert db.ok() and db.info()["fold_mask"] == 0x20202020
