@@ -29,7 +29,7 @@ if os.environ.get("HG_BUILD_OUT"):
     OBJ = LIB + ".obj"
     LIBHS_NAME = os.path.basename(LIB) + ".libhs.so.5"
 
-HIP_SOURCES = ["hg_kernels.hip", "hg_huge.hip", "hg_engine.hip", "hg_capi.hip", "hg_shim.hip", "hg_hsface.hip"]
+HIP_SOURCES = ["hg_stream.hip", "hg_kernels.hip", "hg_huge.hip", "hg_engine.hip", "hg_capi.hip", "hg_shim.hip", "hg_hsface.hip"]
 CXX_SOURCES = ["hg_compile.cpp"]
 HEADERS = ["hg_mem.h", "hg_db.h", "hg_core.h", "hg_post.h", "hg_engine.h", "hg_compile.h", "hg_synth.h", "hg_confirm_dev.h", "hg_sink_dev.h"]
 
@@ -48,10 +48,11 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def _compile_kernels(cmd: list[str]) -> None:
-    """Compile the kernel file with the compiler's per-kernel resource remarks on, keep them next to the library
-    (lib/kernel_resources.json; tests/test_abi.py checks them) and refuse a dword-aligned stream kernel that touches scratch:
-    a by-value argument one field too large once cost 20 % of the pass without failing any test."""
+KERNEL_SOURCES = ("hg_stream.hip", "hg_kernels.hip", "hg_huge.hip")  # their per-kernel resources are recorded
+
+
+def _compile_kernels(cmd: list[str], table_path: str) -> None:
+    """Compile a kernel file with the compiler's per-kernel resource remarks on and keep them next to its object."""
     import json
     import re
 
@@ -74,6 +75,21 @@ def _compile_kernels(cmd: list[str]) -> None:
             table[name] = {}
         elif name:
             table[name][key] = int(value) if value.isdigit() else value
+    with open(table_path, "w", encoding="utf-8") as f:
+        json.dump(table, f, indent=1, sort_keys=True)
+
+
+def _merge_resources() -> None:
+    """lib/kernel_resources.json (tests/test_abi.py checks it) = the kernel files' tables; refuse a dword-aligned stream kernel
+    that touches scratch: a by-value argument one field too large once cost 20 % of the pass without failing any test."""
+    import json
+
+    table = {}
+    for src in KERNEL_SOURCES:
+        path = os.path.join(OBJ, src + ".resources.json")
+        if os.path.exists(path):
+            with open(path, encoding="utf-8") as f:
+                table.update(json.load(f))
     with open(os.path.join(LIB_DIR, "kernel_resources.json"), "w", encoding="utf-8") as f:
         json.dump(table, f, indent=1, sort_keys=True)
     for kernel, res in table.items():
@@ -84,11 +100,13 @@ def _compile_kernels(cmd: list[str]) -> None:
 
 
 def build(verbose: bool = False, force: bool = False) -> str:
+    from concurrent.futures import ThreadPoolExecutor
+
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = _hipcc()
     common_deps = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(REPO, "include", "hypergrep_amd.h")]
-    objs = []
+    objs, jobs = [], []
     for src in HIP_SOURCES + CXX_SOURCES:
         path = os.path.join(CSRC, src)
         if not os.path.exists(path):
@@ -102,10 +120,19 @@ def build(verbose: bool = False, force: bool = False) -> str:
                 cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-Wextra", "-c", path, "-o", obj]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
-            if src == "hg_kernels.hip":
-                _compile_kernels(cmd)
-            else:
-                subprocess.check_call(cmd)
+            jobs.append((src, cmd))
+
+    def run(job) -> None:
+        src, cmd = job
+        if src in KERNEL_SOURCES:
+            _compile_kernels(cmd, os.path.join(OBJ, src + ".resources.json"))
+        else:
+            subprocess.check_call(cmd)
+
+    if jobs:  # the translation units are independent: a few at a time (the stream kernels alone take half a minute)
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as pool:
+            list(pool.map(run, jobs))
+    _merge_resources()
     if force or _stale(LIB, objs + [os.path.join(CSRC, "exports.map")]):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-o", LIB] + objs + ["-lz", "-ldl", "-Wl,-Bsymbolic", "-Wl,-soname,libhyperscanner.so",
                                                                                 "-Wl,--version-script=" + os.path.join(CSRC, "exports.map")]
