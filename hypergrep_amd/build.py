@@ -56,7 +56,7 @@ def _compile_kernels(cmd: list[str], table_path: str) -> None:
     import json
     import re
 
-    proc = subprocess.run(cmd + ["-Rpass-analysis=kernel-resource-usage"], stderr=subprocess.PIPE, text=True)
+    proc = subprocess.run(cmd + ["-Rpass-analysis=kernel-resource-usage", "-fno-caret-diagnostics"], stderr=subprocess.PIPE, text=True)
     remarks, other = [], []
     for line in proc.stderr.splitlines():
         (remarks if "-Rpass-analysis=kernel-resource-usage" in line else other).append(line)
