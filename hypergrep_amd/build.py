@@ -29,9 +29,9 @@ if os.environ.get("HG_BUILD_OUT"):
     OBJ = LIB + ".obj"
     LIBHS_NAME = os.path.basename(LIB) + ".libhs.so.5"
 
-HIP_SOURCES = ["hg_stream.hip", "hg_kernels.hip", "hg_huge.hip", "hg_engine.hip", "hg_capi.hip", "hg_shim.hip", "hg_hsface.hip"]
+HIP_SOURCES = ["hg_stream.hip", "hg_kernels.hip", "hg_always_on.hip", "hg_huge.hip", "hg_engine.hip", "hg_capi.hip", "hg_shim.hip", "hg_hsface.hip"]
 CXX_SOURCES = ["hg_compile.cpp"]
-HEADERS = ["hg_mem.h", "hg_db.h", "hg_core.h", "hg_post.h", "hg_engine.h", "hg_compile.h", "hg_synth.h", "hg_confirm_dev.h", "hg_sink_dev.h"]
+HEADERS = ["hg_mem.h", "hg_db.h", "hg_core.h", "hg_post.h", "hg_engine.h", "hg_compile.h", "hg_synth.h", "hg_confirm_dev.h", "hg_sink_dev.h", "hg_tables_dev.h"]
 
 
 def _hipcc() -> str:
@@ -48,7 +48,7 @@ def _stale(target: str, deps: list[str]) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-KERNEL_SOURCES = ("hg_stream.hip", "hg_kernels.hip", "hg_huge.hip")  # their per-kernel resources are recorded
+KERNEL_SOURCES = ("hg_stream.hip", "hg_kernels.hip", "hg_always_on.hip", "hg_huge.hip")  # their per-kernel resources are recorded
 
 
 def _compile_kernels(cmd: list[str], table_path: str) -> None:

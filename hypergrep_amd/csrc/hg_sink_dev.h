@@ -1,4 +1,4 @@
-// Device-side hit emission shared by the confirm / always-on kernels (hg_kernels.hip) and the huge-automaton kernels
+// Device-side hit emission shared by the confirm / always-on kernels (hg_kernels.hip, hg_always_on.hip) and the huge-automaton kernels
 // (hg_huge.hip): a report goes straight into the finalize bucket of its line's start, or — compact-array mode — into the
 // block's private staging segment that flush_hits() then copies to the compact output.
 #pragma once

@@ -216,6 +216,41 @@ def test_nul_rules_and_edge_inputs(torch_cuda):
         assert got == want and stats.n_lines == nlines
 
 
+ALWAYS_ON_POOL = [
+    "[0-9]+\\.[0-9]+", "\\b[xyz]{2}\\b", " +[a-c]", "[a-c]+=[0-9]", "x.y", "[^a]b", "a.", "\\Bab", "^[a-c]", "[0-9]$", "[a-c]{2,5}x",
+    "(?:ab|c)+z", "\\b[0-9]{3}\\b", "_[a-z]*-", "[xyz]+\\b", "=\\B", "[a-c][0-9][a-c]", "y[^\\n]*z", "\\s[xyz]", "[[:digit:]]+[a-c]", "(?i)xY", "0*1",
+]
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_always_on_tier_multi_tile(torch_cuda, seed):
+    """Expressions without a usable required literal over texts of many tiles (hg_always_on_fast_kernel): lean dword steps in
+    the tiles inside the text, the exact per-byte routine in the last tile, for expressions whose match can include the newline
+    ("a.", "\\s[xyz]") and for small scan buffers; groups of several expressions in one state word with and without boundary
+    conditions; SINGLEMATCH and all-matches flags; lines longer than the lanes' segments and than the scan buffer; NULs."""
+    rng = random.Random(777000 + seed)
+    k = rng.choice([1, 2, 3, 4, 6])
+    pats = [rng.choice(ALWAYS_ON_POOL) for _ in range(k)]
+    flags = [rng.choice([14, 14, 6, 10, 2, 15]) for _ in pats]
+    ids = [rng.randint(0, 2) for _ in pats] if rng.random() < 0.5 else list(range(k))
+    assert oracle_py.check_patterns(pats, flags=flags) == 0
+    maxlen = rng.choice([24, 200])
+    data = bytearray(regex_gen.random_text(rng, rng.choice([1500, 4000]) * (6 if maxlen == 24 else 1), maxlen=maxlen, final_newline=rng.random() < 0.8))
+    if seed % 2:
+        at = rng.randrange(len(data))
+        data[at:at] = bytes(rng.choice(b"abcxyz01 ._-=") for _ in range(rng.choice([700, 5000, 40000])))  # a line longer than a segment
+        for _ in range(rng.randint(0, 6)):
+            data[rng.randrange(len(data))] = 0
+    data = bytes(data)
+    assert len(data) > 3 * 16384
+    for bs in ((262140, 1000) if seed % 4 == 1 else (262140,)):
+        want, nlines = oracle_hits(data, pats, flags, ids, buffer_size=bs)
+        got, stats = gpu_scan_buffer(torch_cuda, data, pats, flags, ids, buffer_size=bs)
+        assert got == want, (pats, flags, ids, bs, len(got), len(want), sorted(set(got) - set(want))[:3], sorted(set(want) - set(got))[:3])
+        assert stats.n_lines == nlines
+    assert _loaded_native()
+
+
 def test_not_singlematch_and_mixed_ids(torch_cuda):
     data = b"aaa needle_in_haystack needle_in_haystack\nba\n"
     pats, flags, ids = ["a", "needle_in_haystack", "needle"], [6, 6, 14], [0, 1, 1]
