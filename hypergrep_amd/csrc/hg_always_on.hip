@@ -635,17 +635,38 @@ __global__ __launch_bounds__(256) void hg_always_on_fast_kernel(HgConfirmArgs a)
       // (aligned 16-byte chunks, SWAR)
       uint32_t cnt = 0, after_last = 0;  // after_last: offset in the tile just past the segment's last newline, 0 = none
       const uint32_t seg = static_cast<uint32_t>(hi - lo), seg_off = static_cast<uint32_t>(lo - tile_start);
-      for (uint32_t b = 0; b < 256; b += 64) {  // 64 bytes per lane at a time (see always_on_word)
-        uint4 v[4];
+      if (__builtin_amdgcn_ballot_w64(seg != 256u) == 0) {  // (wave-uniform) whole segments: a dword at a time, the last newline located once
+        uint32_t last_m = 0, last_at = 0;
+        for (uint32_t b = 0; b < 256; b += 64) {  // 64 bytes per lane at a time (see always_on_word)
+          uint4 v[4];
 #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) v[k] = b + 16 * k < seg ? *reinterpret_cast<const uint4 *>(a.text + lo + b + 16 * k) : make_uint4(0, 0, 0, 0);
+          for (uint32_t k = 0; k < 4; k++) v[k] = *reinterpret_cast<const uint4 *>(a.text + lo + b + 16 * k);
 #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) {
-          const uint32_t at = b + 16 * k;
-          uint32_t m = hgdev::eq_mask16(v[k], 0x0a0a0a0au);
-          if (at + 16 > seg) m &= at < seg ? (1u << (seg - at)) - 1u : 0u;
-          cnt += __popc(m);
-          if (m) after_last = seg_off + at + (31 - __clz(m)) + 1;
+          for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t dw[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+            for (uint32_t d = 0; d < 4; d++) {
+              const uint32_t m = hg_newline_mask(dw[d]);
+              cnt += __popc(m);
+              last_at = m ? b + 16 * k + 4 * d : last_at;
+              last_m = m ? m : last_m;
+            }
+          }
+        }
+        if (last_m) after_last = seg_off + last_at + (4u - (static_cast<uint32_t>(__clz(last_m)) >> 3));
+      } else {
+        for (uint32_t b = 0; b < 256; b += 64) {
+          uint4 v[4];
+#pragma unroll
+          for (uint32_t k = 0; k < 4; k++) v[k] = b + 16 * k < seg ? *reinterpret_cast<const uint4 *>(a.text + lo + b + 16 * k) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+          for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t at = b + 16 * k;
+            uint32_t m = hgdev::eq_mask16(v[k], 0x0a0a0a0au);
+            if (at + 16 > seg) m &= at < seg ? (1u << (seg - at)) - 1u : 0u;
+            cnt += __popc(m);
+            if (m) after_last = seg_off + at + (31 - __clz(m)) + 1;
+          }
         }
       }
       rank_lo = wave_inclusive_scan(cnt, lane) - cnt;
