@@ -25,10 +25,18 @@ __device__ __forceinline__ uint32_t byte_of(const uint4 &v, uint32_t i) {
   return (w >> ((i & 3u) * 8u)) & 0xFFu;
 }
 // 16-bit mask of the bytes of v equal to `c`
+// (the 0x80 flags of a dword become four adjacent bits with ONE v_dot4_u32_u8: sum of 0x80 * weight over the flagged bytes,
+// weights 1 2 4 8 for the even dword of a pair and 16 32 64 128 for the odd one = the byte's bit << 7; the round-2 version
+// extracted and merged the flags bit by bit, 28 vector instructions per chunk in the walks of every confirm routine)
 __device__ __forceinline__ uint32_t eq_mask16(const uint4 &v, uint32_t c4) {
   const uint32_t m0 = hg_zero_bytes(v.x ^ c4), m1 = hg_zero_bytes(v.y ^ c4), m2 = hg_zero_bytes(v.z ^ c4), m3 = hg_zero_bytes(v.w ^ c4);
+#ifdef HG_EQMASK_BITWISE  // (experiment builds: round 2's packing)
   auto pack = [](uint32_t m) { return ((m >> 7) & 1u) | ((m >> 14) & 2u) | ((m >> 21) & 4u) | ((m >> 28) & 8u); };
   return pack(m0) | (pack(m1) << 4) | (pack(m2) << 8) | (pack(m3) << 12);
+#endif
+  const uint32_t lo = __builtin_amdgcn_udot4(m1, 0x80402010u, __builtin_amdgcn_udot4(m0, 0x08040201u, 0u, false), false);
+  const uint32_t hi = __builtin_amdgcn_udot4(m3, 0x80402010u, __builtin_amdgcn_udot4(m2, 0x08040201u, 0u, false), false);
+  return (lo >> 7) | (hi << 1);
 }
 
 // Walks over the line in aligned 16-byte chunks, up to FOUR loads in flight per step: a walk is a chain of dependent memory

@@ -404,11 +404,22 @@ __device__ __forceinline__ void verify_body(const HgConfirmArgs &a, VerifyStage 
 }
 // (the register budgets: beside two stream workgroups — 4 waves of 80 VGPRs per SIMD — a SIMD has 192 VGPRs left; at 64 the
 // pass keeps three waves per SIMD there, at 80 two.  The pass lives on resident waves: every candidate is a chain of fetches.)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void hg_verify_kernel(HgConfirmArgs a) {
+// Waves per SIMD of the side kernels.  They run beside the stream pass, and what they take from it is not issue slots (raising
+// the stream waves' priority changes nothing) but room in the memory pipeline: every resident side wave keeps scattered 16-byte
+// requests in flight.  Config 5, 32 GiB, same box: verify at 8 waves + literal confirm at 7 (its natural count once its line walks
+// pack their byte masks with v_dot4) 14.95 ms, literal confirm capped at 4: 14.3, at 3 with verify at 4: 13.6-13.7, verify at 2: 14.4-14.8
+// (then the side passes are the longer chain).  Config 3 does not notice (6.70-6.78 ms either way).
+#ifndef HG_VERIFY_WAVES
+#define HG_VERIFY_WAVES 4
+#endif
+#ifndef HG_LITERAL_WAVES
+#define HG_LITERAL_WAVES 3
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HG_VERIFY_WAVES, HG_VERIFY_WAVES))) void hg_verify_kernel(HgConfirmArgs a) {
   __shared__ VerifyStage s_stage;
   verify_body<true>(a, &s_stage);
 }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void hg_verify_lean_kernel(HgConfirmArgs a) { verify_body<false>(a, nullptr); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HG_VERIFY_WAVES, HG_VERIFY_WAVES))) void hg_verify_lean_kernel(HgConfirmArgs a) { verify_body<false>(a, nullptr); }
 
 // Confirm passes over the lists of verified occurrences, one routine per confirm mode so that the lanes of a wave do the
 // same work:
@@ -554,6 +565,9 @@ __device__ __forceinline__ void confirm_tables_body(const HgConfirmArgs &a, uint
 // Modes 0..2 in ONE launch (their items are few and each item is a chain of dependent loads: run back to back the three
 // passes cost three latency tails, side by side one): blocks [k * blocks_per_mode, (k+1) * blocks_per_mode) work on the
 // k-th mode present in the database.
+#ifdef HG_CONFIRM_WAVES
+__attribute__((amdgpu_waves_per_eu(HG_CONFIRM_WAVES, HG_CONFIRM_WAVES)))
+#endif
 __global__ __launch_bounds__(HG_CONFIRM_THREADS) void hg_confirm_fast_kernel(HgConfirmArgs a, uint32_t blocks_per_mode) {
   // Launch order = slowest routine first, mode by mode (per-wave timing, tools/confirm_waves.py: a batch of the routine with
   // boundary conditions takes 200-280 us, one of the context-free routine 70, a literal-only one 40; 9216 blocks are 3.6
@@ -585,8 +599,8 @@ __global__ __launch_bounds__(256) void hg_confirm_generic_kernel(HgConfirmArgs a
 // Pattern sets whose anchored expressions are ALL literal-only (config 5's 4096 literals, a single keyword): the routine on its
 // own, at a third of the registers of the three-routine kernel — the pass is a chain of dependent loads per occurrence, and
 // resident waves are what hides them.
-// (its natural register count: capped at 64 for a third wave per SIMD beside the stream pass it spills 164 bytes per lane and takes
-// 2.35 ms per 8 GiB of config 5 instead of 1.3)
+// (held at HG_LITERAL_WAVES waves per SIMD, above: fewer resident side waves leave the stream pass more of the memory pipeline)
+__attribute__((amdgpu_waves_per_eu(HG_LITERAL_WAVES, HG_LITERAL_WAVES)))
 __global__ __launch_bounds__(256) void hg_confirm_literal_kernel(HgConfirmArgs a) { confirm_body<0>(a, blockIdx.x, gridDim.x); }
 
 // ------------------------------------------------------------------------------------------------
