@@ -6,7 +6,6 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/record
 mkdir -p $O
 cd $R
-timeout -k 10 400 python bench.py 2>/dev/null | tail -1 > $O/bench.json || exit 1
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python $R/bench.py --cpu-seconds 0 > $O/trace.log 2>&1 || exit 1
 python $R/tools/kstats.py $O/trace/*/*kernel_stats.csv > $O/kernel_stats.txt
@@ -47,4 +46,8 @@ if f and w:
 print("# FETCH_SIZE is in KB of 64-B requests; on gfx950 a wide coalesced streaming read counts HALF its bytes")
 print("# (MI355X_MICROARCH.md, HBM section): HBM read bytes of hg_stream_kernel = 2 x FETCH_SIZE x 1024.")
 PY
+# the official line last: bench.py prices the roofline fraction with the rocprofv3 duration and the PMC traffic recorded just now
+cp $O/hbm_traffic_latest.json $R/profiles/hbm_traffic_latest.json
+cd $R
+timeout -k 10 400 python bench.py 2>/dev/null | tail -1 > $O/bench.json || exit 1
 cat $O/bench.json; head -12 $O/kernel_stats.txt; cat $O/hbm_traffic.txt
