@@ -342,11 +342,12 @@ struct AoLane {
 };
 template <bool CTX, int NT, bool OWN>
 __device__ __forceinline__ void ao_step(const AlwaysOnCtx &a, const AoUnit &p, const hgdev::lds_u32 *tab, const AoWalk &w, uint32_t off, uint32_t v, AoLane &s,
-                                        uint32_t rank_base) {
+                                        uint32_t rank_base, uint32_t nlacc) {
   const hgdev::lds_u32 *fu = tab + CT_FU, *rxa = tab + CT_RXA;
   const __attribute__((address_space(3))) uint8_t *rxa8 = reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(rxa);
   uint32_t S = s.S;
   uint32_t hb[4];  // accepting nodes met at each byte (CTX: before it)
+  const uint32_t m = hg_newline_mask(v);
   if (CTX) {
     uint32_t cb[4], k[4];
 #pragma unroll
@@ -370,14 +371,22 @@ __device__ __forceinline__ void ao_step(const AlwaysOnCtx &a, const AoUnit &p, c
     uint32_t rc[4];
 #pragma unroll
     for (uint32_t i = 0; i < 4; i++) rc[i] = rxa[(v >> (8 * i)) & 0xFFu];
+    uint32_t Sb[4];  // the state before each byte
 #pragma unroll
     for (uint32_t i = 0; i < 4; i++) {
+      Sb[i] = S;
       S = ao_follow<NT>(fu, S) & rc[i];
       hb[i] = S & p.acc_all;
     }
+    // (wave-uniform, rare: an accepting node consumes the newline, e.g. [0-9]+\s — a match may end WITH its line.  reachL['\n'] is 0,
+    // so what would survive a newline of this dword is looked at here: nlacc = reach['\n'] & the accepting nodes)
+    if (nlacc != 0 && m != 0) {
+#pragma unroll
+      for (uint32_t i = 0; i < 4; i++)
+        if ((m >> (8 * i + 7)) & 1u) hb[i] |= ao_follow<NT>(fu, Sb[i]) & nlacc;
+    }
   }
   s.S = S;
-  const uint32_t m = hg_newline_mask(v);
   if (hb[0] | hb[1] | hb[2] | hb[3]) {  // a match (rare)
     const hgdev::lds_u32 *member = tab + CT_MEMBER, *member_nodes = tab + CT_MEMBER + HG_GROUP_MAX_MEMBERS;
 #pragma unroll
@@ -451,8 +460,9 @@ __device__ __forceinline__ void always_on_word(const AlwaysOnCtx &a, const AoUni
   }
   // The exact routine for the whole walk (wave-uniform) if a lane can meet a forced break (a newline inside the walk puts the next
   // break bs1 bytes past it: beyond `stop` unless the scan buffer is tiny), if the text ends in the wave's tile, or if a match of
-  // the unit can include the newline.
-  const bool careful = w.bs1c <= 512u || tab[CT_NL_ACCEPTS] != 0 || __builtin_amdgcn_ballot_w64(nb_first <= w.stop + 4u || w.text_ends) != 0;
+  // a unit with boundary conditions can include the newline (a context-free unit handles that in its lean steps).
+  const uint32_t nlacc = __builtin_amdgcn_readfirstlane(tab[CT_NL_ACCEPTS]);
+  const bool careful = w.bs1c <= 512u || (CTX && nlacc != 0) || __builtin_amdgcn_ballot_w64(nb_first <= w.stop + 4u || w.text_ends) != 0;
   // the left context of the first byte: a bounded lead-in begins in the middle of a line (every lane of the wave at walk offset 0,
   // but the lanes whose lead-in the start of the text cuts short); a line or piece begins with the START context, which the
   // zeros before it leave behind
@@ -495,10 +505,10 @@ __device__ __forceinline__ void always_on_word(const AlwaysOnCtx &a, const AoUni
     ahead = load64(off + 64);
 #pragma unroll
     for (uint32_t k = 0; k < 4; k++) {
-      ao_step<CTX, NT, false>(a, p, tab, w, off + 16 * k, blk.p[k].x, s, 0);
-      ao_step<CTX, NT, false>(a, p, tab, w, off + 16 * k + 4, blk.p[k].y, s, 0);
-      ao_step<CTX, NT, false>(a, p, tab, w, off + 16 * k + 8, blk.p[k].z, s, 0);
-      ao_step<CTX, NT, false>(a, p, tab, w, off + 16 * k + 12, blk.p[k].w, s, 0);
+      ao_step<CTX, NT, false>(a, p, tab, w, off + 16 * k, blk.p[k].x, s, 0, nlacc);
+      ao_step<CTX, NT, false>(a, p, tab, w, off + 16 * k + 4, blk.p[k].y, s, 0, nlacc);
+      ao_step<CTX, NT, false>(a, p, tab, w, off + 16 * k + 8, blk.p[k].z, s, 0, nlacc);
+      ao_step<CTX, NT, false>(a, p, tab, w, off + 16 * k + 12, blk.p[k].w, s, 0, nlacc);
     }
   }
   const uint32_t rank_base = rank_lo - s.nlc;  // rank of a byte of the own segment = rank_lo + the newlines met since `own`
@@ -507,10 +517,10 @@ __device__ __forceinline__ void always_on_word(const AlwaysOnCtx &a, const AoUni
     ahead = load64(off + 64);
 #pragma unroll
     for (uint32_t k = 0; k < 4; k++) {
-      ao_step<CTX, NT, true>(a, p, tab, w, off + 16 * k, blk.p[k].x, s, rank_base);
-      ao_step<CTX, NT, true>(a, p, tab, w, off + 16 * k + 4, blk.p[k].y, s, rank_base);
-      ao_step<CTX, NT, true>(a, p, tab, w, off + 16 * k + 8, blk.p[k].z, s, rank_base);
-      ao_step<CTX, NT, true>(a, p, tab, w, off + 16 * k + 12, blk.p[k].w, s, rank_base);
+      ao_step<CTX, NT, true>(a, p, tab, w, off + 16 * k, blk.p[k].x, s, rank_base, nlacc);
+      ao_step<CTX, NT, true>(a, p, tab, w, off + 16 * k + 4, blk.p[k].y, s, rank_base, nlacc);
+      ao_step<CTX, NT, true>(a, p, tab, w, off + 16 * k + 8, blk.p[k].z, s, rank_base, nlacc);
+      ao_step<CTX, NT, true>(a, p, tab, w, off + 16 * k + 12, blk.p[k].w, s, rank_base, nlacc);
     }
   }
   if (CTX) {  // the byte after the segment lends its context to a match that ends with the segment
