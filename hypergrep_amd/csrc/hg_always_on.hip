@@ -251,6 +251,14 @@ __device__ __forceinline__ uint32_t ao_break_after(uint32_t piece_start_rel, uin
   const uint32_t at = piece_start_rel + bs1c;  // (both below 2^31)
   return at < 0x7FFFFFFFu ? at : 0xFFFFFFFFu;
 }
+// Follow step without tables: in position order most follow sets are "the next node" (concatenation), "the node itself" (+ / *)
+// and "the node after an optional one" (a b* c: a -> c), so
+//   init | follow(S) = init | (S & M0) | ((S & M1) << 1) | ((S & M2) << 2) | ((S & M3) << 3) | the follow rest of <= 2 exception nodes
+// (the head of an alternation, the way back in a repeated group).  Units of more than 8 nodes that fit take this form in their
+// lean steps: three or four LDS lookups per byte less, which is what a unit with boundary conditions is bound by.
+struct AoShift {
+  uint32_t M0, M1, M2, M3, I, nexc, src0, F0, src1, F1;
+};
 template <int NT>
 __device__ __forceinline__ uint32_t ao_follow(const hgdev::lds_u32 *fu, uint32_t S) {  // init | follow(S)
   uint32_t T = fu[S & 0xFFu];
@@ -261,6 +269,18 @@ __device__ __forceinline__ uint32_t ao_follow(const hgdev::lds_u32 *fu, uint32_t
 }
 
 // The exact routine: the four bytes at walk offset `off`, byte by byte, from the state the previous dword left.
+template <int NT>  // NT == 0: the shift form
+__device__ __forceinline__ uint32_t ao_follow_lean(const hgdev::lds_u32 *fu, const AoShift &sh, uint32_t S) {
+  if (NT != 0) return ao_follow<(NT ? NT : 1)>(fu, S);
+  uint32_t T = ((S & sh.M1) << 1) | sh.I;
+  T |= S & sh.M0;
+  if (sh.M2) T |= (S & sh.M2) << 2;  // (wave-uniform branches)
+  if (sh.M3) T |= (S & sh.M3) << 3;
+  if (sh.nexc > 0) T |= static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int32_t>(S), sh.src0, 1u)) & sh.F0;
+  if (sh.nexc > 1) T |= static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int32_t>(S), sh.src1, 1u)) & sh.F1;
+  return T;
+}
+
 template <bool CTX, int NT>
 __device__ __forceinline__ void ao_exact_dword(const AlwaysOnCtx &a, const AoUnit &p, const hgdev::lds_u32 *tab, const AoWalk &w, uint32_t off, uint32_t v, uint32_t prevc,
                                                uint32_t &S, uint32_t &rank, uint32_t &reported, uint32_t &nb) {
@@ -341,8 +361,8 @@ struct AoLane {
   uint32_t reported, rep_nlc;   // bit m: member m has reported on the line that began after newline number rep_nlc
 };
 template <bool CTX, int NT, bool OWN>
-__device__ __forceinline__ void ao_step(const AlwaysOnCtx &a, const AoUnit &p, const hgdev::lds_u32 *tab, const AoWalk &w, uint32_t off, uint32_t v, AoLane &s,
-                                        uint32_t rank_base, uint32_t nlacc) {
+__device__ __forceinline__ void ao_step(const AlwaysOnCtx &a, const AoUnit &p, const AoShift &sh, const hgdev::lds_u32 *tab, const AoWalk &w, uint32_t off, uint32_t v,
+                                        AoLane &s, uint32_t rank_base, uint32_t nlacc) {
   const hgdev::lds_u32 *fu = tab + CT_FU, *rxa = tab + CT_RXA;
   const __attribute__((address_space(3))) uint8_t *rxa8 = reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(rxa);
   uint32_t S = s.S;
@@ -364,7 +384,7 @@ __device__ __forceinline__ void ao_step(const AlwaysOnCtx &a, const AoUnit &p, c
 #pragma unroll
     for (uint32_t i = 0; i < 4; i++) {
       hb[i] = S & e[i].y;
-      S = ao_follow<NT>(fu, S) & e[i].x;
+      S = ao_follow_lean<NT>(fu, sh, S) & e[i].x;
     }
     s.pcs = k[3];
   } else {
@@ -375,7 +395,7 @@ __device__ __forceinline__ void ao_step(const AlwaysOnCtx &a, const AoUnit &p, c
 #pragma unroll
     for (uint32_t i = 0; i < 4; i++) {
       Sb[i] = S;
-      S = ao_follow<NT>(fu, S) & rc[i];
+      S = ao_follow_lean<NT>(fu, sh, S) & rc[i];
       hb[i] = S & p.acc_all;
     }
     // (wave-uniform, rare: an accepting node consumes the newline, e.g. [0-9]+\s — a match may end WITH its line.  reachL['\n'] is 0,
@@ -383,7 +403,7 @@ __device__ __forceinline__ void ao_step(const AlwaysOnCtx &a, const AoUnit &p, c
     if (nlacc != 0 && m != 0) {
 #pragma unroll
       for (uint32_t i = 0; i < 4; i++)
-        if ((m >> (8 * i + 7)) & 1u) hb[i] |= ao_follow<NT>(fu, Sb[i]) & nlacc;
+        if ((m >> (8 * i + 7)) & 1u) hb[i] |= ao_follow_lean<NT>(fu, sh, Sb[i]) & nlacc;
     }
   }
   s.S = S;
@@ -483,7 +503,7 @@ __device__ __forceinline__ void always_on_word(const AlwaysOnCtx &a, const AoUni
       }
       const uint32_t sel = (off >> 2) & 3u;
       const uint32_t v = sel == 0 ? chunk.x : (sel == 1 ? chunk.y : (sel == 2 ? chunk.z : chunk.w));
-      ao_exact_dword<CTX, NT>(a, p, tab, w, off, v, pv >> 24, S, rank, reported, nb);
+      ao_exact_dword<CTX, (NT ? NT : 4)>(a, p, tab, w, off, v, pv >> 24, S, rank, reported, nb);
       pv = v;
     }
     return;
@@ -495,6 +515,12 @@ __device__ __forceinline__ void always_on_word(const AlwaysOnCtx &a, const AoUni
     for (uint32_t k = 0; k < 4; k++) b.p[k] = load16(at + 16 * k);
     return b;
   };
+  AoShift sh{};
+  if (NT == 0) {
+    const hgdev::lds_u32 *q = tab + CT_SHIFT;
+    auto uni = [&](uint32_t i) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(q[i])); };
+    sh = AoShift{uni(2), uni(1), uni(3), uni(8), p.init_word, uni(0), uni(4), uni(5), uni(6), uni(7)};
+  }
   AoLane s;
   s.S = 0; s.nlc = 0; s.reported = 0; s.rep_nlc = 0;
   s.pcs = CTX ? tab[CT_RXA + 512 + 2 * (pv >> 24)] : 0u;
@@ -505,10 +531,10 @@ __device__ __forceinline__ void always_on_word(const AlwaysOnCtx &a, const AoUni
     ahead = load64(off + 64);
 #pragma unroll
     for (uint32_t k = 0; k < 4; k++) {
-      ao_step<CTX, NT, false>(a, p, tab, w, off + 16 * k, blk.p[k].x, s, 0, nlacc);
-      ao_step<CTX, NT, false>(a, p, tab, w, off + 16 * k + 4, blk.p[k].y, s, 0, nlacc);
-      ao_step<CTX, NT, false>(a, p, tab, w, off + 16 * k + 8, blk.p[k].z, s, 0, nlacc);
-      ao_step<CTX, NT, false>(a, p, tab, w, off + 16 * k + 12, blk.p[k].w, s, 0, nlacc);
+      ao_step<CTX, NT, false>(a, p, sh, tab, w, off + 16 * k, blk.p[k].x, s, 0, nlacc);
+      ao_step<CTX, NT, false>(a, p, sh, tab, w, off + 16 * k + 4, blk.p[k].y, s, 0, nlacc);
+      ao_step<CTX, NT, false>(a, p, sh, tab, w, off + 16 * k + 8, blk.p[k].z, s, 0, nlacc);
+      ao_step<CTX, NT, false>(a, p, sh, tab, w, off + 16 * k + 12, blk.p[k].w, s, 0, nlacc);
     }
   }
   const uint32_t rank_base = rank_lo - s.nlc;  // rank of a byte of the own segment = rank_lo + the newlines met since `own`
@@ -517,10 +543,10 @@ __device__ __forceinline__ void always_on_word(const AlwaysOnCtx &a, const AoUni
     ahead = load64(off + 64);
 #pragma unroll
     for (uint32_t k = 0; k < 4; k++) {
-      ao_step<CTX, NT, true>(a, p, tab, w, off + 16 * k, blk.p[k].x, s, rank_base, nlacc);
-      ao_step<CTX, NT, true>(a, p, tab, w, off + 16 * k + 4, blk.p[k].y, s, rank_base, nlacc);
-      ao_step<CTX, NT, true>(a, p, tab, w, off + 16 * k + 8, blk.p[k].z, s, rank_base, nlacc);
-      ao_step<CTX, NT, true>(a, p, tab, w, off + 16 * k + 12, blk.p[k].w, s, rank_base, nlacc);
+      ao_step<CTX, NT, true>(a, p, sh, tab, w, off + 16 * k, blk.p[k].x, s, rank_base, nlacc);
+      ao_step<CTX, NT, true>(a, p, sh, tab, w, off + 16 * k + 4, blk.p[k].y, s, rank_base, nlacc);
+      ao_step<CTX, NT, true>(a, p, sh, tab, w, off + 16 * k + 8, blk.p[k].z, s, rank_base, nlacc);
+      ao_step<CTX, NT, true>(a, p, sh, tab, w, off + 16 * k + 12, blk.p[k].w, s, rank_base, nlacc);
     }
   }
   if (CTX) {  // the byte after the segment lends its context to a match that ends with the segment
@@ -587,6 +613,24 @@ __device__ __forceinline__ void always_on_stage(hgdev::lds_u32 *tab, const HgCon
     for (uint32_t b = 0; b < 8; b++)
       if (((x >> b) & 1u) && 8 * t + b < nnodes) f |= tab[CT_FOLLOW + 8 * t + b];
     tab[CT_FU + e] = f;
+  }
+  if (tid == 0) {  // the shift form of the follow step, if the unit has one (ao_follow_lean)
+    uint32_t M[4] = {0, 0, 0, 0}, nexc = 0, src[2] = {0, 0}, F[2] = {0, 0};
+    for (uint32_t i = 0; i < nnodes; i++) {
+      uint32_t f = tab[CT_FOLLOW + i];
+      for (uint32_t k = 0; k < 4 && i + k < 32; k++)
+        if (f >> (i + k) & 1u) {
+          M[k] |= 1u << i;
+          f &= ~(1u << (i + k));
+        }
+      if (f) {
+        if (nexc < 2) { src[nexc] = i; F[nexc] = f; }
+        nexc++;
+      }
+    }
+    tab[CT_SHIFT + 0] = nexc <= 2 ? nexc : 0xFFFFFFFFu;
+    tab[CT_SHIFT + 1] = M[1]; tab[CT_SHIFT + 2] = M[0]; tab[CT_SHIFT + 3] = M[2]; tab[CT_SHIFT + 8] = M[3];
+    tab[CT_SHIFT + 4] = src[0]; tab[CT_SHIFT + 5] = F[0]; tab[CT_SHIFT + 6] = src[1]; tab[CT_SHIFT + 7] = F[1];
   }
   if (!ctx) {  // reachL
     const uint32_t c = tid, r = tab[CT_REACH + c];
@@ -716,7 +760,11 @@ __global__ __launch_bounds__(256) void hg_always_on_fast_kernel(HgConfirmArgs a)
         ctx = !p.simple;
       }
       const uint32_t nt = (unit.nnodes + 7u) >> 3;  // follow-union tables in use (wave-uniform)
-      if (ctx) {
+      const bool shift_form = nt >= 2 && tab[CT_SHIFT] <= 2u;
+      if (shift_form) {
+        if (ctx) always_on_word<true, 0>(cx, unit, tab, lo, hi, line_start, a.bs1, rank_lo);
+        else always_on_word<false, 0>(cx, unit, tab, lo, hi, line_start, a.bs1, rank_lo);
+      } else if (ctx) {
         if (nt <= 1) always_on_word<true, 1>(cx, unit, tab, lo, hi, line_start, a.bs1, rank_lo);
         else if (nt == 2) always_on_word<true, 2>(cx, unit, tab, lo, hi, line_start, a.bs1, rank_lo);
         else if (nt == 3) always_on_word<true, 3>(cx, unit, tab, lo, hi, line_start, a.bs1, rank_lo);

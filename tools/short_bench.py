@@ -14,7 +14,9 @@ SETS = (["ERROR"], ["foo|bar"], ["status=5[0-9]{2}"], ["ERROR", "WARN", "panic",
         # huge automata (sparse tables, hg_huge.hip): anchored by a literal (12, 13), always-on (14), among config 3's patterns (15)
         ["status=500.{0,3000}timeout"], ["foo.{0,3000}bar"], ["[a-z]{2000}x"], patterns + ["status=5[0-9]{2}.{0,2000}retry_budget"],
         # 16: an always-on expression whose match can include the newline (an accepting node that consumes it)
-        ["[a-z]+@[a-z]+\\s"])
+        ["[a-z]+@[a-z]+\\s"],
+        # 17, 18: always-on expressions of two state words (33..64 positions): a SHA-1 in hex, a UUID
+        ["[0-9a-f]{40}"], ["[0-9a-f]{8}-[0-9a-f]{4}-[0-9a-f]{4}-[0-9a-f]{4}-[0-9a-f]{12}"])
 for pats in (SETS if len(sys.argv) < 3 else [SETS[int(sys.argv[2])]]):
     nbytes = int(sys.argv[1]) << 30 if len(sys.argv) > 1 else 1 << 30
     text = torch.empty(nbytes + 64, dtype=torch.uint8, device="cuda:0")
