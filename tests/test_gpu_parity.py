@@ -220,10 +220,12 @@ ALWAYS_ON_POOL = [
     "[0-9]+\\.[0-9]+", "\\b[xyz]{2}\\b", " +[a-c]", "[a-c]+=[0-9]", "x.y", "[^a]b", "a.", "\\Bab", "^[a-c]", "[0-9]$", "[a-c]{2,5}x",
     "(?:ab|c)+z", "\\b[0-9]{3}\\b", "_[a-z]*-", "[xyz]+\\b", "=\\B", "[a-c][0-9][a-c]", "y[^\\n]*z", "\\s[xyz]", "[[:digit:]]+[a-c]", "(?i)xY", "0*1",
     "[0-9]+\\s", "x[^y]", "[a-c]+\\W", "\\b[xyz]+\\s",
+    # two state words (33..64 positions)
+    "[^ ]{34}", "[^ =]{36}x?", "[a-z0-9_.-]{33,}", "\\b[^ ]{33}", "[^ ]{20}[a-c][^ ]{20}",
 ]
 
 
-@pytest.mark.parametrize("seed", range(14))
+@pytest.mark.parametrize("seed", range(20))
 def test_always_on_tier_multi_tile(torch_cuda, seed):
     """Expressions without a usable required literal over texts of many tiles (hg_always_on_fast_kernel): lean dword steps in
     the tiles inside the text, the exact per-byte routine in the last tile, for expressions whose match can include the newline
