@@ -563,6 +563,170 @@ __device__ __forceinline__ void always_on_word(const AlwaysOnCtx &a, const AoUni
   }
 }
 
+// ---- two state words (33..64 nodes), context-free, follow step in shift form: the lean walk with 64-bit states --------------
+// (a SHA-1 in hex, a UUID, [^ ]{40}: 250 GiB/s through always_on_segment<2, false>, whose follow step walks the set bits of the
+// state through LDS).  What does not fit — boundary conditions, follow sets outside the shift form, a match that can include the
+// newline — and every wave the lean steps leave out (always_on_word) keeps that routine.
+struct AoShift2 {
+  uint2 M0, M1, M2, M3, I, F0, F1, acc;
+  uint32_t nexc, src0, src1;
+};
+__device__ __forceinline__ uint2 ao_follow2(const AoShift2 &sh, uint2 S) {
+  uint2 a = make_uint2(S.x & sh.M1.x, S.y & sh.M1.y);
+  uint2 T = make_uint2((a.x << 1) | sh.I.x, ((a.y << 1) | (a.x >> 31)) | sh.I.y);
+  T.x |= S.x & sh.M0.x;
+  T.y |= S.y & sh.M0.y;
+  if (sh.M2.x | sh.M2.y) {  // (wave-uniform branches)
+    a = make_uint2(S.x & sh.M2.x, S.y & sh.M2.y);
+    T.x |= a.x << 2;
+    T.y |= (a.y << 2) | (a.x >> 30);
+  }
+  if (sh.M3.x | sh.M3.y) {
+    a = make_uint2(S.x & sh.M3.x, S.y & sh.M3.y);
+    T.x |= a.x << 3;
+    T.y |= (a.y << 3) | (a.x >> 29);
+  }
+  if (sh.nexc > 0) {
+    const uint32_t e = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int32_t>(sh.src0 < 32 ? S.x : S.y), sh.src0 & 31u, 1u));
+    T.x |= e & sh.F0.x;
+    T.y |= e & sh.F0.y;
+  }
+  if (sh.nexc > 1) {
+    const uint32_t e = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int32_t>(sh.src1 < 32 ? S.x : S.y), sh.src1 & 31u, 1u));
+    T.x |= e & sh.F1.x;
+    T.y |= e & sh.F1.y;
+  }
+  return T;
+}
+struct AoLane2 {
+  uint2 S;
+  uint32_t nlc, reported, rep_nlc;
+};
+template <bool OWN>
+__device__ __forceinline__ void ao_step2(const AlwaysOnCtx &a, const AoShift2 &sh, uint32_t pi, bool single, const hgdev::lds_u32 *tab, const AoWalk &w, uint32_t off, uint32_t v,
+                                         AoLane2 &s, uint32_t rank_base) {
+  const __attribute__((address_space(3))) uint8_t *r8 = reinterpret_cast<const __attribute__((address_space(3))) uint8_t *>(tab + CT_RXA);
+  uint2 rc[4];
+#pragma unroll
+  for (uint32_t i = 0; i < 4; i++) {
+    const hgdev::lds_u32 *e = reinterpret_cast<const hgdev::lds_u32 *>(r8 + (((v >> (8 * i)) & 0xFFu) << 3));
+    rc[i] = make_uint2(e[0], e[1]);
+  }
+  uint2 S = s.S;
+  uint32_t hb[4];
+#pragma unroll
+  for (uint32_t i = 0; i < 4; i++) {
+    const uint2 T = ao_follow2(sh, S);
+    S = make_uint2(T.x & rc[i].x, T.y & rc[i].y);
+    hb[i] = (S.x & sh.acc.x) | (S.y & sh.acc.y);
+  }
+  s.S = S;
+  const uint32_t m = hg_newline_mask(v);
+  if (hb[0] | hb[1] | hb[2] | hb[3]) {  // a match (rare)
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+      if (!hb[i]) continue;
+      const uint32_t line = s.nlc + __popc(m & ((1u << (8 * i)) - 1u));  // newlines before this byte: its line
+      if (s.rep_nlc != line) s.reported = 0;
+      if (single && s.reported) continue;
+      s.reported = 1;
+      s.rep_nlc = line;
+      if (OWN) always_on_note(a, pi, w.base + off + i + 1, rank_base + line);
+    }
+  }
+  s.nlc += __popc(m);
+}
+__device__ __forceinline__ void always_on_word2(const AlwaysOnCtx &a, const HgPattern &p, uint32_t pi, const hgdev::lds_u32 *tab, uint64_t lo, uint64_t hi,
+                                                uint64_t line_start, uint64_t bs1, uint32_t rank_lo) {
+  // the walk's geometry and the decision for the exact routine: as always_on_word
+  const uint8_t *text = a.text;
+  const bool bounded = p.max_len && p.max_len <= HG_ALWAYS_ON_FAST_MAX_LEN;  // wave-uniform
+  uint64_t q = line_start;
+  if (bounded) {
+    const uint32_t lead = p.max_len - 1;
+    q = lo > lead ? lo - lead : 0;
+  } else if (lo - line_start >= bs1) {
+    q = line_start + (lo - line_start) / bs1 * bs1;
+  }
+  const uint64_t q64 = q & ~63ull;
+  const uint32_t lead64 = lo < hi ? static_cast<uint32_t>(lo - q64) : 0u;
+  uint32_t own = lead64;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t other = __shfl_xor(own, o, 64);
+    own = other > own ? other : own;
+  }
+  own = __builtin_amdgcn_readfirstlane(own);
+  AoWalk w;
+  w.base = lo - own;
+  w.own = own;
+  w.stop = own + static_cast<uint32_t>(hi - lo);
+  w.bs1c = bs1 < 0x7FFFFFFFull ? static_cast<uint32_t>(bs1) : 0x7FFFFFFFu;
+  w.text_ends = hi >= a.nbytes;
+  const uint32_t start64 = own - lead64;
+  uint32_t nb_first;
+  if (q64 >= line_start) {
+    const uint64_t d = q64 - line_start, k = d <= bs1 ? 1 : (d + bs1 - 1) / bs1;
+    const uint64_t at = line_start + k * bs1 - w.base;
+    nb_first = at < 0x7FFFFFFFull ? static_cast<uint32_t>(at) : 0xFFFFFFFFu;
+  } else {
+    const uint64_t at = line_start + bs1 - w.base;
+    nb_first = at < 0x7FFFFFFFull ? static_cast<uint32_t>(at) : 0xFFFFFFFFu;
+  }
+  const hgdev::lds_u32 *q2 = tab + CT_SHIFT + 16;
+  auto uni = [&](uint32_t i) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(q2[i])); };
+  const uint32_t nexc = uni(0);
+  const bool careful = nexc > 2u || w.bs1c <= 512u || __builtin_amdgcn_ballot_w64(nb_first <= w.stop + 4u || w.text_ends) != 0;
+  if (careful) {
+    always_on_segment<2, false>(a, p, pi, tab, lo, hi, line_start, bs1, rank_lo);
+    return;
+  }
+  AoShift2 sh;
+  sh.nexc = nexc;
+  sh.M0 = make_uint2(uni(1), uni(2)); sh.M1 = make_uint2(uni(3), uni(4)); sh.M2 = make_uint2(uni(5), uni(6)); sh.M3 = make_uint2(uni(7), uni(8));
+  sh.src0 = uni(9); sh.F0 = make_uint2(uni(10), uni(11)); sh.src1 = uni(12); sh.F1 = make_uint2(uni(13), uni(14));
+  sh.I = make_uint2(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(tab[CT_INIT])), static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(tab[CT_INIT + 1])));
+  sh.acc = make_uint2(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(tab[CT_ACC])), static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(tab[CT_ACC + 1])));
+  auto load16 = [&](uint32_t at) {
+    return (at >= start64 && at <= w.stop && w.base + at < a.nbytes) ? *reinterpret_cast<const uint4 *>(text + w.base + at) : make_uint4(0, 0, 0, 0);
+  };
+  struct Block { uint4 p[4]; };
+  auto load64 = [&](uint32_t at) {
+    Block b;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) b.p[k] = load16(at + 16 * k);
+    return b;
+  };
+  const bool single = p.single != 0;
+  AoLane2 s;
+  s.S = make_uint2(0, 0); s.nlc = 0; s.reported = 0; s.rep_nlc = 0;
+  uint32_t off = 0;
+  Block ahead = load64(0);
+  for (; off < own; off += 64) {  // the lead-in
+    const Block blk = ahead;
+    ahead = load64(off + 64);
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+      ao_step2<false>(a, sh, pi, single, tab, w, off + 16 * k, blk.p[k].x, s, 0);
+      ao_step2<false>(a, sh, pi, single, tab, w, off + 16 * k + 4, blk.p[k].y, s, 0);
+      ao_step2<false>(a, sh, pi, single, tab, w, off + 16 * k + 8, blk.p[k].z, s, 0);
+      ao_step2<false>(a, sh, pi, single, tab, w, off + 16 * k + 12, blk.p[k].w, s, 0);
+    }
+  }
+  const uint32_t rank_base = rank_lo - s.nlc;
+  for (; off < own + 256u; off += 64) {
+    const Block blk = ahead;
+    ahead = load64(off + 64);
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+      ao_step2<true>(a, sh, pi, single, tab, w, off + 16 * k, blk.p[k].x, s, rank_base);
+      ao_step2<true>(a, sh, pi, single, tab, w, off + 16 * k + 4, blk.p[k].y, s, rank_base);
+      ao_step2<true>(a, sh, pi, single, tab, w, off + 16 * k + 8, blk.p[k].z, s, rank_base);
+      ao_step2<true>(a, sh, pi, single, tab, w, off + 16 * k + 12, blk.p[k].w, s, rank_base);
+    }
+  }
+}
+
 // Tables of one unit, staged by the whole workgroup (the caller brackets this with __syncthreads): reach / follow / context
 // tables as the database holds them, then what the lean steps read.
 __device__ __forceinline__ void always_on_stage(hgdev::lds_u32 *tab, const HgConfirmArgs &a, uint32_t u, uint32_t tid) {
@@ -603,7 +767,42 @@ __device__ __forceinline__ void always_on_stage(hgdev::lds_u32 *tab, const HgCon
     one_word = nw == 1;
     ctx = !p.simple;
   }
-  if (!one_word) return;
+  if (!one_word) {  // two state words: can the unit take the lean walk (always_on_word2)?
+    __syncthreads();
+    if (tid == 0) {
+      // context-free: every context enters and accepts the same nodes
+      bool same = true;
+      for (uint32_t k = 1; k < 16; k++) same = same && tab[CT_AMASK + 2 * k] == tab[CT_AMASK] && tab[CT_AMASK + 2 * k + 1] == tab[CT_AMASK + 1];
+      for (uint32_t k = 1; k < 20; k++) same = same && tab[CT_ACC + 2 * k] == tab[CT_ACC] && tab[CT_ACC + 2 * k + 1] == tab[CT_ACC + 1];
+      // ... and no match includes the newline
+      const uint32_t nl0 = tab[CT_REACH + 2 * '\n'] & tab[CT_AMASK] & tab[CT_ACC], nl1 = tab[CT_REACH + 2 * '\n' + 1] & tab[CT_AMASK + 1] & tab[CT_ACC + 1];
+      uint64_t M0 = 0, M1 = 0, M2 = 0, M3 = 0, F0 = 0, F1 = 0;
+      uint32_t nexc = 0, src0 = 0, src1 = 0;
+      for (uint32_t i = 0; i < nnodes; i++) {
+        uint64_t f = tab[CT_FOLLOW + 2 * i] | (static_cast<uint64_t>(tab[CT_FOLLOW + 2 * i + 1]) << 32);
+        const uint64_t self = 1ull << i;
+        if (f & self) { M0 |= self; f &= ~self; }
+        if (i + 1 < 64 && (f >> (i + 1) & 1ull)) { M1 |= self; f &= ~(1ull << (i + 1)); }
+        if (i + 2 < 64 && (f >> (i + 2) & 1ull)) { M2 |= self; f &= ~(1ull << (i + 2)); }
+        if (i + 3 < 64 && (f >> (i + 3) & 1ull)) { M3 |= self; f &= ~(1ull << (i + 3)); }
+        if (f) {
+          if (nexc == 0) { src0 = i; F0 = f; }
+          if (nexc == 1) { src1 = i; F1 = f; }
+          nexc++;
+        }
+      }
+      hgdev::lds_u32 *q = tab + CT_SHIFT + 16;
+      q[0] = (same && !(nl0 | nl1) && nexc <= 2) ? nexc : 0xFFFFFFFFu;
+      q[1] = static_cast<uint32_t>(M0); q[2] = static_cast<uint32_t>(M0 >> 32); q[3] = static_cast<uint32_t>(M1); q[4] = static_cast<uint32_t>(M1 >> 32);
+      q[5] = static_cast<uint32_t>(M2); q[6] = static_cast<uint32_t>(M2 >> 32); q[7] = static_cast<uint32_t>(M3); q[8] = static_cast<uint32_t>(M3 >> 32);
+      q[9] = src0; q[10] = static_cast<uint32_t>(F0); q[11] = static_cast<uint32_t>(F0 >> 32); q[12] = src1; q[13] = static_cast<uint32_t>(F1); q[14] = static_cast<uint32_t>(F1 >> 32);
+    }
+    // reachL2[c] = the nodes byte c may enter (0 at NUL and the newline: a line ends there)
+    const uint32_t c = tid;
+    tab[CT_RXA + 2 * c] = (c == 0 || c == '\n') ? 0u : (tab[CT_REACH + 2 * c] & tab[CT_AMASK]);
+    tab[CT_RXA + 2 * c + 1] = (c == 0 || c == '\n') ? 0u : (tab[CT_REACH + 2 * c + 1] & tab[CT_AMASK + 1]);
+    return;
+  }
   __syncthreads();
   // follow unions fu[t][x] = union of follow[8t + b] over the set bits b of x; the init nodes ride in table 0
   for (uint32_t e = tid; e < 1024; e += 256) {
@@ -753,7 +952,7 @@ __global__ __launch_bounds__(256) void hg_always_on_fast_kernel(HgConfirmArgs a)
         const uint32_t pi = a.db.slow[a.db.nslow_grouped + (u - ngroups)];
         const HgPattern &p = a.db.patterns[pi];
         if (!p.simple && p.nw != 1) {
-          always_on_segment<2, false>(cx, p, pi, tab, lo, hi, line_start, a.bs1, rank_lo);
+          always_on_word2(cx, p, pi, tab, lo, hi, line_start, a.bs1, rank_lo);
           continue;
         }
         unit = AoUnit{p.init_word, p.acc_all, p.max_len, 1u, p.single ? 1u : 0u, p.nnodes};

@@ -13,4 +13,5 @@ constexpr uint32_t CT_MEMBER = CT_WORDS + 1024;      // member pattern indices [
 constexpr uint32_t CT_NL_ACCEPTS = CT_INIT + 3;      // != 0: a match of the staged unit can include the newline
 constexpr uint32_t CT_RXA = CT_WORDS + 1024 + 2 * HG_GROUP_MAX_MEMBERS;  // lean steps: {RX, AX}[4 classes][256] (class 1 = the class of every byte), or reachL[256]
 constexpr uint32_t CT_SHIFT = CT_RXA + 2048;         // shift form of the follow step: exception count (> 2: none), M1, M0, M2, src0, F0, src1, F1, M3
-constexpr uint32_t AO_TAB_WORDS = CT_SHIFT + 12;      // the table area of hg_always_on_fast_kernel
+// (+16..: the same for a unit of two state words: flag, M0 M1 M2 M3 (lo, hi), src0, F0 (lo, hi), src1, F1 (lo, hi); its reachL2[256][2] sits at CT_RXA)
+constexpr uint32_t AO_TAB_WORDS = CT_SHIFT + 32;      // the table area of hg_always_on_fast_kernel
