@@ -222,10 +222,11 @@ ALWAYS_ON_POOL = [
     "[0-9]+\\s", "x[^y]", "[a-c]+\\W", "\\b[xyz]+\\s",
     # two state words (33..64 positions)
     "[^ ]{34}", "[^ =]{36}x?", "[a-z0-9_.-]{33,}", "\\b[^ ]{33}", "[^ ]{20}[a-c][^ ]{20}",
+    "(?:ab|c)[^ ]{35}", "[^ ]{16}x?[^ ]{20}", "[^ ]{12}(?:[a-c][0-9])*[^ ]{24}", "[^ ]{30}[^ ]?[^ ]?[^ ]?y",
 ]
 
 
-@pytest.mark.parametrize("seed", range(20))
+@pytest.mark.parametrize("seed", range(26))
 def test_always_on_tier_multi_tile(torch_cuda, seed):
     """Expressions without a usable required literal over texts of many tiles (hg_always_on_fast_kernel): lean dword steps in
     the tiles inside the text, the exact per-byte routine in the last tile, for expressions whose match can include the newline
