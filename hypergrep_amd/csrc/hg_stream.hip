@@ -573,7 +573,7 @@ __global__ __launch_bounds__(WG_THREADS) __attribute__((amdgpu_waves_per_eu(HG_S
     const uint4 *__restrict__ text16, uint64_t nbytes, uint64_t tile_begin, uint64_t tile_end, const uint4 *__restrict__ filter16, const uint4 *__restrict__ ext16, uint32_t fold,
     uint32_t wa, uint32_t wb, HgTileSum *__restrict__ sums, HgCand *__restrict__ cands, uint32_t seg_cap, uint32_t *__restrict__ seg_count, uint32_t *__restrict__ counters,
     uint32_t cursor_slot) {
-#ifdef HG_STREAM_PRIO
+#ifdef HG_STREAM_PRIO  // (experiment builds: a higher wave priority next to the side kernels changed nothing, profiles/r03_experiments.txt)
   __builtin_amdgcn_s_setprio(HG_STREAM_PRIO);
 #endif
   stream_body<LOG2, WIDE, DENSE, DEPTH, false, FOLD>(text16, nbytes, tile_begin, tile_end, filter16, ext16, fold, wa, wb, sums, cands, seg_cap, seg_count, counters, cursor_slot);
